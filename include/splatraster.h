@@ -1,0 +1,124 @@
+/*
+ * splatraster.h -- C ABI of libsplatraster.so, the MI355X (gfx950) differentiable
+ * Gaussian-splat rasterizer that replaces the `diff_gaussian_rasterization._C` extension
+ * SplatFields imports at reference gaussian_renderer/__init__.py:14.
+ *
+ * Every entry point takes plain pointers and sizes; no torch / C++ types cross this boundary.
+ * All device memory (inputs, outputs, gradients, the three opaque state buffers) is owned by
+ * the caller (PyTorch-ROCm tensors, `tensor.data_ptr()`); the library owns nothing persistent.
+ * Every kernel is launched on the caller-supplied HIP stream.  Functions return 0 on success,
+ * a non-zero status otherwise; `sr_last_error()` returns a thread-local message.
+ *
+ * Which upstream interface each entry replaces ([EXT] = the pip dependency
+ * ingra14m/depth-diff-gaussian-rasterization@f2d8fa9, reference README.md:28, not vendored):
+ *
+ *   sr_forward_prepare + sr_forward_render
+ *        <- [EXT] `_C.rasterize_gaussians(...)`, reached from `GaussianRasterizer.forward`
+ *           called at reference gaussian_renderer/__init__.py:94-102 and :106-114.
+ *   sr_backward
+ *        <- [EXT] `_C.rasterize_gaussians_backward(...)`, reached from autograd when
+ *           reference train.py:252 runs `loss.backward()`.
+ *   sr_mark_visible
+ *        <- [EXT] `_C.mark_visible(...)` (`GaussianRasterizer.markVisible`; never called by
+ *           SplatFields, exported for completeness).
+ *   SrView
+ *        <- the 12-field `GaussianRasterizationSettings` built at reference
+ *           gaussian_renderer/__init__.py:59-72 (and :76-89 for the alpha pass).
+ *   SrSplats
+ *        <- the keyword arguments of the call at reference gaussian_renderer/__init__.py:94-102.
+ *   geom / binning / image buffers
+ *        <- [EXT] geomBuffer / binningBuffer / imgBuffer saved by the autograd ctx.
+ *
+ * Conventions: viewmatrix / projmatrix are the *transposed* matrices of
+ * reference scene/cameras.py:68-73 stored contiguously, i.e. element [i][j] at ptr[4*i+j] and
+ * p_hom = [x y z 1] @ M; quaternions are (r,x,y,z) used as given; scales and opacities are
+ * already activated; SH is [N,K,3] coefficient-major.
+ */
+#ifndef SPLATRASTER_H
+#define SPLATRASTER_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_VERSION 1
+#define SR_TILE 16 /* binning tile edge in pixels (upstream BLOCK_X = BLOCK_Y) */
+
+typedef struct SrView {
+    int image_height;
+    int image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int sh_degree;            /* active SH degree, 0..3 */
+    int sh_coeffs;            /* K = coefficients stored per splat (shs.shape[1]); 0 with precomputed colours */
+    int prefiltered;
+    int debug;                /* non-zero: synchronise + check after every launch */
+    const float* viewmatrix;  /* device, 16 floats */
+    const float* projmatrix;  /* device, 16 floats */
+    const float* campos;      /* device, 3 floats */
+    const float* bg;          /* device, 3 floats */
+} SrView;
+
+typedef struct SrSplats {
+    int count;                   /* N */
+    const float* means3D;        /* device [N,3] */
+    const float* opacities;      /* device [N] (the [N,1] tensor, contiguous) */
+    const float* scales;         /* device [N,3]; NULL iff cov3D_precomp is given */
+    const float* rotations;      /* device [N,4]; NULL iff cov3D_precomp is given */
+    const float* cov3D_precomp;  /* device [N,6] (xx,xy,xz,yy,yz,zz) or NULL */
+    const float* shs;            /* device [N,K,3] or NULL */
+    const float* colors_precomp; /* device [N,3] or NULL (exactly one of shs / colors_precomp) */
+} SrSplats;
+
+/* Dense per-splat gradient outputs, all written in full by sr_backward (culled splats get zeros). */
+typedef struct SrGrads {
+    float* dL_dmeans3D;   /* [N,3] */
+    float* dL_dmeans2D;   /* [N,3]; [:, :2] in the upstream NDC-scaled convention (x 0.5*W, 0.5*H), [:,2] = 0 */
+    float* dL_dopacity;   /* [N]   */
+    float* dL_dscales;    /* [N,3] or NULL with cov3D_precomp */
+    float* dL_drotations; /* [N,4] or NULL with cov3D_precomp */
+    float* dL_dcov3D;     /* [N,6] or NULL unless cov3D_precomp */
+    float* dL_dshs;       /* [N,K,3] or NULL */
+    float* dL_dcolors;    /* [N,3] or NULL */
+} SrGrads;
+
+int sr_version(void);
+const char* sr_last_error(void);
+
+/* Sizes (bytes) of the caller-allocated opaque buffers.  `instances` is the value
+ * sr_forward_prepare returned for this view. */
+size_t sr_geom_bytes(int n_splats, int height, int width);
+size_t sr_binning_bytes(long long instances, int height, int width);
+size_t sr_image_bytes(int height, int width);
+size_t sr_backward_scratch_bytes(long long instances);
+
+/* Stage 1: cull, 3D->2D covariance projection (EWA), conic, radius, tile rectangle, SH->RGB,
+ * per-tile instance counts and their prefix sums.  Writes `radii` [N] (int32) and the geom buffer.
+ * Blocks on the stream once to read back the number of tile-splat instances. */
+int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, int* radii,
+                       long long* instances_out, void* hip_stream);
+
+/* Stage 2: bucket instances per tile, sort each tile's list front-to-back (depth, then splat
+ * index), alpha-composite.  Writes out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W]
+ * (= 1 - final transmittance; may be NULL) plus the binning and image state buffers. */
+int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, void* binning,
+                      long long instances, void* image, float* out_color, float* out_depth,
+                      float* out_alpha, void* hip_stream);
+
+/* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero). */
+int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
+                long long instances, const void* image, const int* radii, const float* dL_dcolor,
+                const float* dL_ddepth, const float* dL_dalpha, void* scratch, const SrGrads* grads,
+                void* hip_stream);
+
+/* present[i] = 1 iff splat i passes the near-plane test (view z > 0.2). */
+int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
+                    const float* projmatrix, unsigned char* present, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLATRASTER_H */

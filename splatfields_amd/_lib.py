@@ -1,0 +1,73 @@
+"""ctypes binding of the C ABI declared in include/splatraster.h.
+
+The product path has no CPU fallback: if libsplatraster.so is missing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libsplatraster.so"
+
+c_float_p = C.c_void_p  # raw device pointers travel as integers
+
+
+class SrView(C.Structure):
+    _fields_ = [("image_height", C.c_int), ("image_width", C.c_int), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+                ("scale_modifier", C.c_float), ("sh_degree", C.c_int), ("sh_coeffs", C.c_int), ("prefiltered", C.c_int),
+                ("debug", C.c_int), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("bg", C.c_void_p)]
+
+
+class SrSplats(C.Structure):
+    _fields_ = [("count", C.c_int), ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p)]
+
+
+class SrGrads(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p)]
+
+
+# every symbol include/splatraster.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sr_version": (C.c_int, []),
+    "sr_last_error": (C.c_char_p, []),
+    "sr_geom_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sr_binning_bytes": (C.c_size_t, [C.c_longlong, C.c_int, C.c_int]),
+    "sr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "sr_backward_scratch_bytes": (C.c_size_t, [C.c_longlong]),
+    "sr_forward_prepare": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_longlong), C.c_void_p]),
+    "sr_forward_render": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_backward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrGrads),
+                              C.c_void_p]),
+    "sr_mark_visible": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libsplatraster.so once; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m splatfields_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise RuntimeError("libsplatraster: " + load().sr_last_error().decode("utf-8", "replace"))

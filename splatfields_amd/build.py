@@ -1,0 +1,43 @@
+"""Builds libsplatraster.so (hand-written HIP kernels + C ABI) for gfx950, in-tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libsplatraster.so"
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip"]
+HEADERS = ["common.h", "kernels.h", "expand.h", "../../include/splatraster.h"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libsplatraster.so cannot be built")
+    return exe
+
+
+def is_stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 ... -> splatfields_amd/libsplatraster.so (cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,157 @@
+// C ABI of libsplatraster.so (see include/splatraster.h for what each entry replaces).
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const std::string& msg) { g_last_error = msg; return 1; }
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return fail(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
+int after_launch(const SrView* view, hipStream_t st, const char* what) {
+    SR_TRY(check_hip(hipGetLastError(), what));
+    if (view && view->debug) SR_TRY(check_hip(hipStreamSynchronize(st), what));
+    return 0;
+}
+
+int validate(const SrView* view, const SrSplats* s) {
+    if (!view || !s) return fail("null view/splats");
+    if (s->count < 0) return fail("negative splat count");
+    if (view->image_height <= 0 || view->image_width <= 0) return fail("image size must be positive");
+    if (!view->viewmatrix || !view->projmatrix || !view->campos || !view->bg) return fail("viewmatrix/projmatrix/campos/bg must be device pointers");
+    if (s->count > 0) {
+        if (!s->means3D || !s->opacities) return fail("means3D/opacities missing");
+        const bool has_sr = s->scales && s->rotations;
+        if (has_sr == (s->cov3D_precomp != nullptr)) return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        if ((s->shs != nullptr) == (s->colors_precomp != nullptr)) return fail("Please provide excatly one of either SHs or precomputed colors!");
+        if (s->shs) {
+            if (view->sh_degree < 0 || view->sh_degree > 3) return fail("sh_degree must be 0..3");
+            if (view->sh_coeffs < (view->sh_degree + 1) * (view->sh_degree + 1)) return fail("shs holds fewer coefficients than sh_degree needs");
+        }
+    }
+    if ((sr::tiles_x(view->image_width) > 65535) || (sr::tiles_y(view->image_height) > 65535)) return fail("image too large");
+    return 0;
+}
+
+sr::ViewK make_view(const SrView* v) {
+    sr::ViewK k;
+    k.H = v->image_height; k.W = v->image_width;
+    k.gx = sr::tiles_x(k.W); k.gy = sr::tiles_y(k.H);
+    k.tanfovx = v->tanfovx; k.tanfovy = v->tanfovy;
+    k.focal_x = k.W / (2.0f * v->tanfovx); k.focal_y = k.H / (2.0f * v->tanfovy);
+    k.scale_modifier = v->scale_modifier;
+    k.sh_degree = v->sh_degree; k.sh_coeffs = v->sh_coeffs;
+    k.viewmatrix = v->viewmatrix; k.projmatrix = v->projmatrix; k.campos = v->campos; k.bg = v->bg;
+    return k;
+}
+
+sr::SplatsK make_splats(const SrSplats* s) {
+    sr::SplatsK k;
+    k.N = s->count; k.means3D = s->means3D; k.opacities = s->opacities; k.scales = s->scales;
+    k.rotations = s->rotations; k.cov3D = s->cov3D_precomp; k.shs = s->shs; k.colors = s->colors_precomp;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_version(void) { return SR_VERSION; }
+const char* sr_last_error(void) { return g_last_error.c_str(); }
+
+size_t sr_geom_bytes(int n, int h, int w) { return sr::carve_geom(nullptr, n, h, w, nullptr); }
+size_t sr_binning_bytes(long long r, int, int) { return sr::carve_binning(nullptr, r, nullptr); }
+size_t sr_image_bytes(int h, int w) { return sr::carve_image(nullptr, h, w, nullptr); }
+size_t sr_backward_scratch_bytes(long long r) { return sr::align_up((size_t)(r > 0 ? r : 1) * sr::kSlotFloats * sizeof(float), 256); }
+
+int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, int* radii,
+                       long long* instances_out, void* hip_stream) {
+    SR_TRY(validate(view, splats));
+    if (!geom || !instances_out || (splats->count > 0 && !radii)) return fail("null geom/radii/instances_out");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::ViewK v = make_view(view);
+    const sr::SplatsK s = make_splats(splats);
+    sr::Geom g;
+    sr::carve_geom(geom, s.N, v.H, v.W, &g);
+    const int nb = (s.N + sr::kBlock - 1) / sr::kBlock;
+    sr::launch_preprocess(v, s, g, radii, st);
+    SR_TRY(after_launch(view, st, "preprocess"));
+    sr::launch_scan_small(g, nb, v.gx * v.gy, st);
+    SR_TRY(after_launch(view, st, "scan"));
+    uint32_t total = 0;
+    SR_TRY(check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(check_hip(hipStreamSynchronize(st), "sync after prepare"));
+    *instances_out = (long long)total;
+    return 0;
+}
+
+int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, void* binning,
+                      long long instances, void* image, float* out_color, float* out_depth,
+                      float* out_alpha, void* hip_stream) {
+    SR_TRY(validate(view, splats));
+    if (!geom || !binning || !image || !out_color || !out_depth) return fail("null buffer");
+    if (instances < 0 || instances >= (1ll << 32)) return fail("instance count out of range");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::ViewK v = make_view(view);
+    const sr::SplatsK s = make_splats(splats);
+    sr::Geom g; sr::Binning b; sr::Image im;
+    sr::carve_geom(geom, s.N, v.H, v.W, &g);
+    sr::carve_binning(binning, instances, &b);
+    sr::carve_image(image, v.H, v.W, &im);
+    sr::launch_emit(v, s.N, g, b, st);
+    SR_TRY(after_launch(view, st, "emit"));
+    sr::launch_sort_tiles(v, g, b, st);
+    SR_TRY(after_launch(view, st, "sort_tiles"));
+    sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st);
+    SR_TRY(after_launch(view, st, "render_forward"));
+    return 0;
+}
+
+int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
+                long long instances, const void* image, const int* radii, const float* dL_dcolor,
+                const float* dL_ddepth, const float* dL_dalpha, void* scratch, const SrGrads* grads,
+                void* hip_stream) {
+    SR_TRY(validate(view, splats));
+    if (!geom || !binning || !image || !dL_dcolor || !scratch || !grads) return fail("null buffer");
+    if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
+    if (splats->count > 0 && splats->shs && !grads->dL_dshs) return fail("dL_dshs missing");
+    if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
+    if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
+    if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::ViewK v = make_view(view);
+    const sr::SplatsK s = make_splats(splats);
+    sr::Geom g; sr::Binning b; sr::Image im;
+    sr::carve_geom(const_cast<void*>(geom), s.N, v.H, v.W, &g);
+    sr::carve_binning(const_cast<void*>(binning), instances, &b);
+    sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
+    float* slots = static_cast<float*>(scratch);
+    sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
+    SR_TRY(after_launch(view, st, "render_backward"));
+    sr::GradsK gr;
+    gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
+    gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
+    gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
+    gr.shs = s.shs ? grads->dL_dshs : nullptr; gr.colors = s.colors ? grads->dL_dcolors : nullptr;
+    sr::launch_preprocess_backward(v, s, g, radii, slots, gr, st);
+    SR_TRY(after_launch(view, st, "preprocess_backward"));
+    return 0;
+}
+
+int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const float*, unsigned char* present, void* hip_stream) {
+    if (n < 0 || (n > 0 && (!means3D || !viewmatrix || !present))) return fail("bad arguments to sr_mark_visible");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    sr::launch_mark_visible(n, means3D, viewmatrix, present, st);
+    return check_hip(hipGetLastError(), "mark_visible");
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// Internal definitions shared by the gfx950 kernels of libsplatraster.so.
+// Semantics restated from SURVEY.md Appendix A (published 3DGS tile rasterizer + depth output).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/splatraster.h"
+
+namespace sr {
+
+// ---- constants of the algorithm (one place; the oracle mirrors them) ----------------------
+constexpr int kTile = SR_TILE;          // binning tile edge
+constexpr int kSub = 8;                 // one wavefront renders an 8x8 sub-tile
+constexpr float kNearCullZ = 0.2f;
+constexpr float kDilation = 0.3f;
+constexpr float kClampFov = 1.3f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTStop = 0.0001f;
+constexpr float kWEps = 0.0000001f;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+constexpr int kBlock = 256;             // threads per workgroup everywhere (4 wavefronts of 64)
+constexpr int kWave = 64;
+
+// per-splat flag bits written by the forward preprocess
+constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampTx = 8, kFlagClampTy = 16;
+
+// ---- carved views of the caller-owned opaque buffers ---------------------------------------
+struct Geom {
+    float4* rec0;        // [N] (pix.x, pix.y, cull half-extent x, cull half-extent y)
+    float4* rec1;        // [N] (conic A, B, C, opacity)
+    float4* rec2;        // [N] (r, g, b, view depth)
+    ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
+    uint32_t* touched;   // [N] instances emitted by this splat
+    uint32_t* offsets;   // [N] exclusive prefix of `touched`
+    uint8_t* flags;      // [N]
+    uint32_t* block_sums;    // [ceil(N/256)]
+    uint32_t* block_offsets; // [ceil(N/256)]
+    uint32_t* tile_count;    // [tiles]
+    uint32_t* tile_start;    // [tiles+1]
+    uint32_t* tile_cursor;   // [tiles]
+    uint32_t* total;         // [1] number of instances
+};
+
+struct Binning {
+    uint64_t* keys;      // [R] (depth bits << 32) | instance index, bucketed per tile, unsorted
+    uint32_t* vals;      // [R] splat index
+    uint64_t* keys_tmp;  // [R] ping-pong for the long-list merge path
+    uint32_t* vals_tmp;  // [R]
+    uint32_t* sorted_id;   // [R] splat index, per tile front-to-back
+    uint32_t* sorted_inst; // [R] instance index (slot of the backward scratch)
+};
+
+struct Image {
+    float* final_T;      // [H*W]
+    uint32_t* n_contrib; // [H*W]
+};
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off;
+    template <typename T> __host__ T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+inline int tiles_x(int W) { return (W + kTile - 1) / kTile; }
+inline int tiles_y(int H) { return (H + kTile - 1) / kTile; }
+
+inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
+    Carver c{static_cast<char*>(base), 0};
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    const size_t nb = (n + kBlock - 1) / kBlock;
+    const size_t tiles = (size_t)tiles_x(W) * tiles_y(H);
+    Geom t;
+    t.rec0 = c.take<float4>(n); t.rec1 = c.take<float4>(n); t.rec2 = c.take<float4>(n);
+    t.rect = c.take<ushort4>(n);
+    t.touched = c.take<uint32_t>(n); t.offsets = c.take<uint32_t>(n);
+    t.flags = c.take<uint8_t>(n);
+    t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
+    t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);
+    t.tile_cursor = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
+    if (g) *g = t;
+    return align_up(c.off, 256);
+}
+
+inline size_t carve_binning(void* base, long long R, Binning* b) {
+    Carver c{static_cast<char*>(base), 0};
+    const size_t r = (size_t)(R > 0 ? R : 1);
+    Binning t;
+    t.keys = c.take<uint64_t>(r); t.vals = c.take<uint32_t>(r);
+    t.keys_tmp = c.take<uint64_t>(r); t.vals_tmp = c.take<uint32_t>(r);
+    t.sorted_id = c.take<uint32_t>(r); t.sorted_inst = c.take<uint32_t>(r);
+    if (b) *b = t;
+    return align_up(c.off, 256);
+}
+
+inline size_t carve_image(void* base, int H, int W, Image* im) {
+    Carver c{static_cast<char*>(base), 0};
+    const size_t px = (size_t)H * W;
+    Image t;
+    t.final_T = c.take<float>(px); t.n_contrib = c.take<uint32_t>(px);
+    if (im) *im = t;
+    return align_up(c.off, 256);
+}
+
+// One record of the backward scratch: per tile-splat instance, the tile-reduced moment sums.
+// (S0, Sx, Sy, Sxx | Sxy, Syy, dr, dg | db, ddepth, pad, pad)
+constexpr int kSlotFloats = 12;
+
+// ---- per-view constants, passed to kernels by value ----------------------------------------
+struct ViewK {
+    int H, W, gx, gy;
+    float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+    int sh_degree, sh_coeffs;
+    const float* viewmatrix; const float* projmatrix; const float* campos; const float* bg;
+};
+
+// ---- device helpers -------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+    // lanes whose row is masked off (or whose source is invalid) add `old` = 0
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+// Sum over the 64 lanes of a wavefront; the total is valid in lane 63 only.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add<0x124>(v);       // row_ror:4
+    v = dpp_add<0x128>(v);       // row_ror:8   -> every lane holds its row-of-16 sum
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Inclusive prefix sum across a wavefront (unsigned).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// Exclusive prefix sum over the 256 threads of a workgroup; `total` is returned to every thread.
+// `scratch` must hold >= 8 uint32_t of LDS.  Contains two __syncthreads().
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t& total) {
+    const uint32_t inc = wave_inclusive_scan(v);
+    const int w = wave_id();
+    __syncthreads();  // protect scratch reuse across calls
+    if (lane_id() == 63) scratch[w] = inc;
+    __syncthreads();
+    const uint32_t s0 = scratch[0], s1 = scratch[1], s2 = scratch[2], s3 = scratch[3];
+    total = s0 + s1 + s2 + s3;
+    const uint32_t wave_base = (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+    return wave_base + inc - v;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const int lane = lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// The alpha of one (pixel, splat) pair -- shared by forward and backward so both make the same
+// skip decisions.  Returns false when the pair is skipped (power > 0 or alpha < 1/255).
+__device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_o, float& G, float& alpha) {
+    const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;
+    G = __expf(power);
+    alpha = fminf(kAlphaMax, con_o.w * G);
+    return (power <= 0.0f) && (alpha >= kAlphaMin);
+}
+
+// Conservative test: can the splat reach any pixel centre of the 8x8 block whose first pixel is (sx, sy)?
+__device__ __forceinline__ bool subtile_overlap(const float4 r0, float sx, float sy) {
+    return (r0.z >= 0.0f) && (r0.x + r0.z >= sx) && (r0.x - r0.z <= sx + (kSub - 1)) &&
+           (r0.y + r0.w >= sy) && (r0.y - r0.w <= sy + (kSub - 1));
+}
+
+#endif  // __HIPCC__
+
+}  // namespace sr

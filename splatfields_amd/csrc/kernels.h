@@ -1,0 +1,34 @@
+// Host-side launchers of the gfx950 kernels (one translation unit per pipeline stage).
+#pragma once
+#include "common.h"
+
+namespace sr {
+
+struct SplatsK {
+    int N;
+    const float* means3D; const float* opacities; const float* scales; const float* rotations;
+    const float* cov3D; const float* shs; const float* colors;
+};
+
+struct GradsK {
+    float* means3D; float* means2D; float* opacity; float* scales; float* rotations; float* cov3D;
+    float* shs; float* colors;
+};
+
+// preprocess.hip
+void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st);
+void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t st);
+void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
+                                const float* slots, const GradsK& gr, hipStream_t st);
+// binning.hip
+void launch_scan_small(const Geom& g, int n_blocks, int n_tiles, hipStream_t st);
+void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st);
+void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, hipStream_t st);
+// render.hip
+void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+                           float* out_color, float* out_depth, float* out_alpha, hipStream_t st);
+void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                            float* slots, hipStream_t st);
+
+}  // namespace sr

@@ -1,0 +1,448 @@
+// Per-splat stages of the rasterizer for gfx950: forward preprocess (cull, 3D->2D covariance
+// projection, conic, radius, tile rectangle, SH->RGB, per-tile instance counting), the
+// near-plane visibility mark, and the backward preprocess (segmented reduction of the per-instance
+// gradient slots + chain rule to means3D / scales / rotations / SH / opacity).
+//
+// Semantics: SURVEY.md Appendix A ("Forward preprocess", "Backward preprocess"), i.e. the
+// published 3DGS rasterizer that reference gaussian_renderer/__init__.py:94-102 calls.
+// One thread per splat, 256-thread workgroups; all traffic is per-splat streaming (HBM-bound).
+#include "kernels.h"
+#include "expand.h"
+
+namespace sr {
+
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+
+__device__ __forceinline__ void quat_to_rot(const float4 q, float R[9]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;  // (r,x,y,z) used as given
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag(s^2) R^T
+__device__ __forceinline__ Sym3 cov3d_from(const float3 s, const float R[9]) {
+    const float a = s.x * s.x, b = s.y * s.y, c = s.z * s.z;
+    Sym3 S;
+    S.xx = R[0] * R[0] * a + R[1] * R[1] * b + R[2] * R[2] * c;
+    S.xy = R[0] * R[3] * a + R[1] * R[4] * b + R[2] * R[5] * c;
+    S.xz = R[0] * R[6] * a + R[1] * R[7] * b + R[2] * R[8] * c;
+    S.yy = R[3] * R[3] * a + R[4] * R[4] * b + R[5] * R[5] * c;
+    S.yz = R[3] * R[6] * a + R[4] * R[7] * b + R[5] * R[8] * c;
+    S.zz = R[6] * R[6] * a + R[7] * R[7] * b + R[8] * R[8] * c;
+    return S;
+}
+
+__device__ __forceinline__ float3 sym_mul(const Sym3& S, const float3 v) {
+    return make_float3(S.xx * v.x + S.xy * v.y + S.xz * v.z,
+                       S.xy * v.x + S.yy * v.y + S.yz * v.z,
+                       S.xz * v.x + S.yz * v.y + S.zz * v.z);
+}
+__device__ __forceinline__ float dot3(const float3 a, const float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Shared by forward and backward: the two rows of M = J * R_view, and the (clamped) t used in J.
+struct Ewa {
+    float3 m0, m1;     // rows of the 2x3 matrix mapping world covariance to screen covariance
+    float tx, ty, tz;  // view-space position with the +-1.3 tanfov clamp applied to x/z, y/z
+    bool clamp_x, clamp_y;
+};
+
+__device__ __forceinline__ Ewa ewa_setup(const float3 pv, const ViewK& v, const float* vm) {
+    Ewa e;
+    const float limx = kClampFov * v.tanfovx, limy = kClampFov * v.tanfovy;
+    const float txtz = pv.x / pv.z, tytz = pv.y / pv.z;
+    e.clamp_x = (txtz < -limx) || (txtz > limx);
+    e.clamp_y = (tytz < -limy) || (tytz > limy);
+    e.tx = fminf(limx, fmaxf(-limx, txtz)) * pv.z;
+    e.ty = fminf(limy, fmaxf(-limy, tytz)) * pv.z;
+    e.tz = pv.z;
+    const float j00 = v.focal_x / e.tz, j02 = -(v.focal_x * e.tx) / (e.tz * e.tz);
+    const float j11 = v.focal_y / e.tz, j12 = -(v.focal_y * e.ty) / (e.tz * e.tz);
+    // R_view[r][c] = vm[4c + r]
+    const float3 r0 = make_float3(vm[0], vm[4], vm[8]);
+    const float3 r1 = make_float3(vm[1], vm[5], vm[9]);
+    const float3 r2 = make_float3(vm[2], vm[6], vm[10]);
+    e.m0 = make_float3(j00 * r0.x + j02 * r2.x, j00 * r0.y + j02 * r2.y, j00 * r0.z + j02 * r2.z);
+    e.m1 = make_float3(j11 * r1.x + j12 * r2.x, j11 * r1.y + j12 * r2.y, j11 * r1.z + j12 * r2.z);
+    return e;
+}
+
+__device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
+    const float x = d.x, y = d.y, z = d.z;
+    B[0] = SH_C0;
+    if (deg > 0) {
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = SH_C2_0 * xy; B[5] = SH_C2_1 * yz; B[6] = SH_C2_2 * (2.f * zz - xx - yy);
+            B[7] = SH_C2_3 * xz; B[8] = SH_C2_4 * (xx - yy);
+            if (deg > 2) {
+                B[9] = SH_C3_0 * y * (3.f * xx - yy); B[10] = SH_C3_1 * xy * z;
+                B[11] = SH_C3_2 * y * (4.f * zz - xx - yy); B[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                B[13] = SH_C3_4 * x * (4.f * zz - xx - yy); B[14] = SH_C3_5 * z * (xx - yy);
+                B[15] = SH_C3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward preprocess
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
+    __shared__ uint32_t s_off[kBlock + 1];
+    __shared__ ushort4 s_rect[kBlock];
+    __shared__ uint32_t s_scan[8];
+
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const float* vm = v.viewmatrix;
+    const float* pm = v.projmatrix;
+    uint32_t touched = 0;
+    ushort4 rect = make_ushort4(0, 0, 0, 0);
+
+    if (idx < s.N) {
+        int out_radius = 0;
+        uint8_t flags = 0;
+        const float3 p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
+        const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
+                                      vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13],
+                                      vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14]);
+        if (pv.z > kNearCullZ) {
+            const float hx_ = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+            const float hy_ = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+            const float hw_ = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+            const float inv_w = 1.0f / (hw_ + kWEps);
+            const float ndc_x = hx_ * inv_w, ndc_y = hy_ * inv_w;
+
+            Sym3 S;
+            if (s.cov3D) {
+                const float* c = s.cov3D + 6 * (size_t)idx;
+                S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
+            } else {
+                float R[9];
+                const float4 q = reinterpret_cast<const float4*>(s.rotations)[idx];
+                quat_to_rot(q, R);
+                const float m = v.scale_modifier;
+                S = cov3d_from(make_float3(m * s.scales[3 * idx], m * s.scales[3 * idx + 1], m * s.scales[3 * idx + 2]), R);
+            }
+            const Ewa e = ewa_setup(pv, v, vm);
+            if (e.clamp_x) flags |= kFlagClampTx;
+            if (e.clamp_y) flags |= kFlagClampTy;
+            const float3 Sm0 = sym_mul(S, e.m0), Sm1 = sym_mul(S, e.m1);
+            const float a = dot3(e.m0, Sm0) + kDilation;
+            const float b = dot3(e.m0, Sm1);
+            const float c = dot3(e.m1, Sm1) + kDilation;
+            const float det = a * c - b * b;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+                const float mid = 0.5f * (a + c);
+                const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.0f * sqrtf(lam));
+                const float px = ((ndc_x + 1.0f) * v.W - 1.0f) * 0.5f;
+                const float py = ((ndc_y + 1.0f) * v.H - 1.0f) * 0.5f;
+                // upstream tile rectangle (3-sigma bounding square), max exclusive
+                const int uxmin = min(v.gx, max(0, (int)((px - my_radius) / kTile)));
+                const int uymin = min(v.gy, max(0, (int)((py - my_radius) / kTile)));
+                const int uxmax = min(v.gx, max(0, (int)((px + my_radius + kTile - 1) / kTile)));
+                const int uymax = min(v.gy, max(0, (int)((py + my_radius + kTile - 1) / kTile)));
+                if ((uxmax - uxmin) * (uymax - uymin) > 0) {
+                    out_radius = (int)my_radius;
+                    const float opac = s.opacities[idx];
+                    // exact support of alpha >= 1/255:  d^T Q d <= 2 ln(255 o)  ->  |dx| <= sqrt(tau * a)
+                    float ex = -1.0f, ey = -1.0f;
+                    const float tau = 2.0f * __logf(255.0f * opac);
+                    if (tau > 0.0f) {
+                        ex = sqrtf(tau * a) * 1.002f + 0.02f;
+                        ey = sqrtf(tau * c) * 1.002f + 0.02f;
+                    }
+                    int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+                    if (ex >= 0.0f) {
+                        // tiles containing a pixel centre within the support box, intersected with upstream's rect
+                        xmin = max(uxmin, (int)floorf(fmaxf(px - ex, 0.0f) / kTile));
+                        ymin = max(uymin, (int)floorf(fmaxf(py - ey, 0.0f) / kTile));
+                        xmax = (px + ex < 0.0f) ? 0 : min(uxmax, (int)floorf((px + ex) / kTile) + 1);
+                        ymax = (py + ey < 0.0f) ? 0 : min(uymax, (int)floorf((py + ey) / kTile) + 1);
+                        if (xmax <= xmin || ymax <= ymin) { xmin = ymin = xmax = ymax = 0; }
+                    }
+                    rect = make_ushort4((unsigned short)xmin, (unsigned short)ymin, (unsigned short)xmax, (unsigned short)ymax);
+                    touched = (uint32_t)((xmax - xmin) * (ymax - ymin));
+
+                    float3 rgb;
+                    if (s.colors) {
+                        rgb = make_float3(s.colors[3 * idx], s.colors[3 * idx + 1], s.colors[3 * idx + 2]);
+                    } else {
+                        const float* cp = v.campos;
+                        float3 d = make_float3(p.x - cp[0], p.y - cp[1], p.z - cp[2]);
+                        const float inv_len = 1.0f / sqrtf(dot3(d, d));
+                        d.x *= inv_len; d.y *= inv_len; d.z *= inv_len;
+                        float B[16];
+                        sh_basis(v.sh_degree, d, B);
+                        const float* sh = s.shs + (size_t)idx * v.sh_coeffs * 3;
+                        const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
+                        rgb = make_float3(0.f, 0.f, 0.f);
+                        for (int k = 0; k < nb; ++k) {
+                            rgb.x += B[k] * sh[3 * k]; rgb.y += B[k] * sh[3 * k + 1]; rgb.z += B[k] * sh[3 * k + 2];
+                        }
+                        rgb.x += 0.5f; rgb.y += 0.5f; rgb.z += 0.5f;
+                        if (rgb.x < 0.f) { flags |= kFlagClampR; rgb.x = 0.f; }
+                        if (rgb.y < 0.f) { flags |= kFlagClampG; rgb.y = 0.f; }
+                        if (rgb.z < 0.f) { flags |= kFlagClampB; rgb.z = 0.f; }
+                    }
+                    g.rec0[idx] = make_float4(px, py, ex, ey);
+                    g.rec1[idx] = make_float4(cA, cB, cC, opac);
+                    g.rec2[idx] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
+                }
+            }
+        }
+        radii[idx] = out_radius;
+        g.rect[idx] = rect;
+        g.touched[idx] = touched;
+        g.flags[idx] = flags;
+    }
+
+    // per-tile instance counts (block-cooperative expansion keeps large splats from serialising a lane)
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
+    s_off[threadIdx.x] = excl;
+    s_rect[threadIdx.x] = rect;
+    if (threadIdx.x == 0) { s_off[kBlock] = total; g.block_sums[blockIdx.x] = total; }
+    __syncthreads();
+    for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
+        atomicAdd(&g.tile_count[tile], 1u);
+    });
+}
+
+void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st) {
+    const int nb = (s.N + kBlock - 1) / kBlock;
+    hipMemsetAsync(g.tile_count, 0, sizeof(uint32_t) * (size_t)v.gx * v.gy, st);
+    if (nb > 0) hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+}
+
+// ------------------------------------------------------------------------------------------
+// markVisible
+// ------------------------------------------------------------------------------------------
+__global__ void k_mark_visible(int N, const float* __restrict__ means3D, const float* __restrict__ vm,
+                               unsigned char* __restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N) return;
+    const float z = vm[2] * means3D[3 * idx] + vm[6] * means3D[3 * idx + 1] + vm[10] * means3D[3 * idx + 2] + vm[14];
+    present[idx] = z > kNearCullZ ? 1 : 0;
+}
+
+void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t st) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(k_mark_visible, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, means3D, viewmatrix, present);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward preprocess
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
+                                                                const int* __restrict__ radii,
+                                                                const float* __restrict__ slots, const GradsK gr) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= s.N) return;
+    const float* vm = v.viewmatrix;
+    const float* pm = v.projmatrix;
+    const int K = v.sh_coeffs;
+
+    float3 d_mean = make_float3(0.f, 0.f, 0.f);
+    float3 d_scale = make_float3(0.f, 0.f, 0.f);
+    float4 d_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d_opac = 0.f;
+    float2 d_m2d = make_float2(0.f, 0.f);
+    float3 d_rgb = make_float3(0.f, 0.f, 0.f);
+    float d_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool visible = radii[idx] > 0;
+
+    float3 p = make_float3(0.f, 0.f, 0.f);
+    uint8_t flags = 0;
+    if (visible) {
+        // ---- segmented reduction of this splat's instance slots (deterministic order) ----
+        float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dd = 0.f;
+        const uint32_t first = g.offsets[idx], cnt = g.touched[idx];
+        const float4* sl = reinterpret_cast<const float4*>(slots) + (size_t)first * 3;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 a = sl[3 * k], b = sl[3 * k + 1], c = sl[3 * k + 2];
+            S0 += a.x; Sx += a.y; Sy += a.z; Sxx += a.w;
+            Sxy += b.x; Syy += b.y; dr += b.z; dg += b.w;
+            db += c.x; dd += c.y;
+        }
+        flags = g.flags[idx];
+        const float4 r1 = g.rec1[idx];
+        const float A = r1.x, B = r1.y, C = r1.z, o = r1.w;
+        d_opac = S0;
+        d_rgb = make_float3(dr, dg, db);
+        // dL/d(NDC mean): (0.5 W, 0.5 H) scaled, the convention scene/gaussian_model.py:427-438 consumes
+        d_m2d.x = -o * (A * Sx + B * Sy) * (0.5f * v.W);
+        d_m2d.y = -o * (B * Sx + C * Sy) * (0.5f * v.H);
+        // conic gradients; .y is half of the true dL/dB (off-diagonal counted once, used twice below)
+        const float dcon_x = -0.5f * o * Sxx, dcon_y = -0.5f * o * Sxy, dcon_z = -0.5f * o * Syy;
+
+        p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
+        const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
+                                      vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13],
+                                      vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14]);
+        Sym3 S;
+        float R[9];
+        float3 sc = make_float3(0.f, 0.f, 0.f);
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.cov3D) {
+            const float* c = s.cov3D + 6 * (size_t)idx;
+            S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
+        } else {
+            q = reinterpret_cast<const float4*>(s.rotations)[idx];
+            quat_to_rot(q, R);
+            const float m = v.scale_modifier;
+            sc = make_float3(m * s.scales[3 * idx], m * s.scales[3 * idx + 1], m * s.scales[3 * idx + 2]);
+            S = cov3d_from(sc, R);
+        }
+        const Ewa e = ewa_setup(pv, v, vm);
+        const float3 Sm0 = sym_mul(S, e.m0), Sm1 = sym_mul(S, e.m1);
+        const float a = dot3(e.m0, Sm0) + kDilation;
+        const float b = dot3(e.m0, Sm1);
+        const float c = dot3(e.m1, Sm1) + kDilation;
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * dcon_x + 2.f * b * c * dcon_y + (denom - a * c) * dcon_z);
+            dL_dc = denom2inv * (-a * a * dcon_z + 2.f * a * b * dcon_y + (denom - a * c) * dcon_x);
+            dL_db = denom2inv * 2.f * (b * c * dcon_x - (denom + 2.f * b * b) * dcon_y + a * b * dcon_z);
+        }
+        // gradient w.r.t. the 6 unique entries of Sigma (off-diagonals appear twice in the quadratic form)
+        const float3 m0 = e.m0, m1 = e.m1;
+        d_cov[0] = m0.x * m0.x * dL_da + m0.x * m1.x * dL_db + m1.x * m1.x * dL_dc;
+        d_cov[3] = m0.y * m0.y * dL_da + m0.y * m1.y * dL_db + m1.y * m1.y * dL_dc;
+        d_cov[5] = m0.z * m0.z * dL_da + m0.z * m1.z * dL_db + m1.z * m1.z * dL_dc;
+        d_cov[1] = 2.f * m0.x * m0.y * dL_da + (m0.x * m1.y + m0.y * m1.x) * dL_db + 2.f * m1.x * m1.y * dL_dc;
+        d_cov[2] = 2.f * m0.x * m0.z * dL_da + (m0.x * m1.z + m0.z * m1.x) * dL_db + 2.f * m1.x * m1.z * dL_dc;
+        d_cov[4] = 2.f * m0.y * m0.z * dL_da + (m0.y * m1.z + m0.z * m1.y) * dL_db + 2.f * m1.y * m1.z * dL_dc;
+
+        // gradient w.r.t. the rows of M, then J, then t
+        const float3 dm0 = make_float3(2.f * dL_da * Sm0.x + dL_db * Sm1.x, 2.f * dL_da * Sm0.y + dL_db * Sm1.y, 2.f * dL_da * Sm0.z + dL_db * Sm1.z);
+        const float3 dm1 = make_float3(2.f * dL_dc * Sm1.x + dL_db * Sm0.x, 2.f * dL_dc * Sm1.y + dL_db * Sm0.y, 2.f * dL_dc * Sm1.z + dL_db * Sm0.z);
+        const float3 rv0 = make_float3(vm[0], vm[4], vm[8]);
+        const float3 rv1 = make_float3(vm[1], vm[5], vm[9]);
+        const float3 rv2 = make_float3(vm[2], vm[6], vm[10]);
+        const float dJ00 = dot3(dm0, rv0), dJ02 = dot3(dm0, rv2), dJ11 = dot3(dm1, rv1), dJ12 = dot3(dm1, rv2);
+        const float tz = 1.f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = (e.clamp_x ? 0.f : 1.f) * -v.focal_x * tz2 * dJ02;
+        const float dty = (e.clamp_y ? 0.f : 1.f) * -v.focal_y * tz2 * dJ12;
+        const float dtz = -v.focal_x * tz2 * dJ00 - v.focal_y * tz2 * dJ11 +
+                          (2.f * v.focal_x * e.tx) * tz3 * dJ02 + (2.f * v.focal_y * e.ty) * tz3 * dJ12;
+        // view rotation transposed; plus the depth output: depth = (row 2 of R_view) . p + const
+        const float dz_total = dtz + dd;
+        d_mean.x = vm[0] * dtx + vm[1] * dty + vm[2] * dz_total;
+        d_mean.y = vm[4] * dtx + vm[5] * dty + vm[6] * dz_total;
+        d_mean.z = vm[8] * dtx + vm[9] * dty + vm[10] * dz_total;
+
+        // screen-space mean -> 3D mean through the perspective divide (with the +1e-7)
+        const float hx_ = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+        const float hy_ = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+        const float hw_ = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+        const float m_w = 1.0f / (hw_ + kWEps);
+        const float mul1 = hx_ * m_w * m_w, mul2 = hy_ * m_w * m_w;
+        d_mean.x += (pm[0] * m_w - pm[3] * mul1) * d_m2d.x + (pm[1] * m_w - pm[3] * mul2) * d_m2d.y;
+        d_mean.y += (pm[4] * m_w - pm[7] * mul1) * d_m2d.x + (pm[5] * m_w - pm[7] * mul2) * d_m2d.y;
+        d_mean.z += (pm[8] * m_w - pm[11] * mul1) * d_m2d.x + (pm[9] * m_w - pm[11] * mul2) * d_m2d.y;
+
+        // Sigma -> scales, quaternion
+        if (!s.cov3D) {
+            // G = dL/dSigma as a full symmetric matrix (off-diagonals halved)
+            const float Gxx = d_cov[0], Gxy = 0.5f * d_cov[1], Gxz = 0.5f * d_cov[2], Gyy = d_cov[3], Gyz = 0.5f * d_cov[4], Gzz = d_cov[5];
+            // Sigma = L L^T, L = R diag(s):  dL/dL = 2 G L ;  L[i][k] = R[i][k] s_k
+            const float sv[3] = {sc.x, sc.y, sc.z};
+            float dLm[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float l0 = R[k] * sv[k], l1 = R[3 + k] * sv[k], l2 = R[6 + k] * sv[k];
+                dLm[k] = 2.f * (Gxx * l0 + Gxy * l1 + Gxz * l2);
+                dLm[3 + k] = 2.f * (Gxy * l0 + Gyy * l1 + Gyz * l2);
+                dLm[6 + k] = 2.f * (Gxz * l0 + Gyz * l1 + Gzz * l2);
+            }
+            const float m = v.scale_modifier;
+            d_scale.x = m * (R[0] * dLm[0] + R[3] * dLm[3] + R[6] * dLm[6]);
+            d_scale.y = m * (R[1] * dLm[1] + R[4] * dLm[4] + R[7] * dLm[7]);
+            d_scale.z = m * (R[2] * dLm[2] + R[5] * dLm[5] + R[8] * dLm[8]);
+            float D[9];  // dL/dR[i][k] = dL/dL[i][k] * s_k
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { D[3 * i] = dLm[3 * i] * sv[0]; D[3 * i + 1] = dLm[3 * i + 1] * sv[1]; D[3 * i + 2] = dLm[3 * i + 2] * sv[2]; }
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            d_rot.x = 2.f * (-z * D[1] + y * D[2] + z * D[3] - x * D[5] - y * D[6] + x * D[7]);
+            d_rot.y = 2.f * (y * D[1] + z * D[2] + y * D[3] - 2.f * x * D[4] - r * D[5] + z * D[6] + r * D[7] - 2.f * x * D[8]);
+            d_rot.z = 2.f * (-2.f * y * D[0] + x * D[1] + r * D[2] + x * D[3] + z * D[5] - r * D[6] + z * D[7] - 2.f * y * D[8]);
+            d_rot.w = 2.f * (-2.f * z * D[0] - r * D[1] + x * D[2] + r * D[3] - 2.f * z * D[4] + y * D[5] + x * D[6] + y * D[7]);
+        }
+    }
+
+    // ---- colour: SH coefficients and view direction, or precomputed colours ----
+    if (gr.shs) {
+        float* out = gr.shs + (size_t)idx * K * 3;
+        int nb = 0;
+        if (visible) {
+            nb = (v.sh_degree + 1) * (v.sh_degree + 1);
+            float3 dc = d_rgb;
+            if (flags & kFlagClampR) dc.x = 0.f;
+            if (flags & kFlagClampG) dc.y = 0.f;
+            if (flags & kFlagClampB) dc.z = 0.f;
+            const float* cp = v.campos;
+            const float3 dv = make_float3(p.x - cp[0], p.y - cp[1], p.z - cp[2]);
+            const float inv_len = 1.0f / sqrtf(dot3(dv, dv));
+            const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
+            float B[16];
+            sh_basis(v.sh_degree, d, B);
+            const float* sh = s.shs + (size_t)idx * K * 3;
+            float gk[16];  // gk[k] = sh[k] . dL/dRGB
+            for (int k = 0; k < nb; ++k) {
+                out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z;
+                gk[k] = sh[3 * k] * dc.x + sh[3 * k + 1] * dc.y + sh[3 * k + 2] * dc.z;
+            }
+            float3 dd_ = make_float3(0.f, 0.f, 0.f);  // dL/d(unit direction)
+            if (v.sh_degree > 0) {
+                const float x = d.x, y = d.y, z = d.z;
+                dd_.x += -SH_C1 * gk[3]; dd_.y += -SH_C1 * gk[1]; dd_.z += SH_C1 * gk[2];
+                if (v.sh_degree > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dd_.x += SH_C2_0 * y * gk[4] + SH_C2_2 * -2.f * x * gk[6] + SH_C2_3 * z * gk[7] + SH_C2_4 * 2.f * x * gk[8];
+                    dd_.y += SH_C2_0 * x * gk[4] + SH_C2_1 * z * gk[5] + SH_C2_2 * -2.f * y * gk[6] + SH_C2_4 * -2.f * y * gk[8];
+                    dd_.z += SH_C2_1 * y * gk[5] + SH_C2_2 * 4.f * z * gk[6] + SH_C2_3 * x * gk[7];
+                    if (v.sh_degree > 2) {
+                        dd_.x += SH_C3_0 * 6.f * xy * gk[9] + SH_C3_1 * yz * gk[10] + SH_C3_2 * -2.f * xy * gk[11] +
+                                 SH_C3_3 * -6.f * xz * gk[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * gk[13] +
+                                 SH_C3_5 * 2.f * xz * gk[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * gk[15];
+                        dd_.y += SH_C3_0 * (3.f * xx - 3.f * yy) * gk[9] + SH_C3_1 * xz * gk[10] +
+                                 SH_C3_2 * (4.f * zz - xx - 3.f * yy) * gk[11] + SH_C3_3 * -6.f * yz * gk[12] +
+                                 SH_C3_4 * -2.f * xy * gk[13] + SH_C3_5 * -2.f * yz * gk[14] + SH_C3_6 * -6.f * xy * gk[15];
+                        dd_.z += SH_C3_1 * xy * gk[10] + SH_C3_2 * 8.f * yz * gk[11] +
+                                 SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * gk[12] + SH_C3_4 * 8.f * xz * gk[13] +
+                                 SH_C3_5 * (xx - yy) * gk[14];
+                    }
+                }
+                // through the normalisation d = dv / |dv|
+                const float proj = dot3(d, dd_);
+                d_mean.x += (dd_.x - d.x * proj) * inv_len;
+                d_mean.y += (dd_.y - d.y * proj) * inv_len;
+                d_mean.z += (dd_.z - d.z * proj) * inv_len;
+            }
+        }
+        for (int k = nb; k < K; ++k) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+    }
+    if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
+
+    gr.means3D[3 * idx] = d_mean.x; gr.means3D[3 * idx + 1] = d_mean.y; gr.means3D[3 * idx + 2] = d_mean.z;
+    gr.means2D[3 * idx] = d_m2d.x; gr.means2D[3 * idx + 1] = d_m2d.y; gr.means2D[3 * idx + 2] = 0.f;
+    gr.opacity[idx] = d_opac;
+    if (gr.scales) { gr.scales[3 * idx] = d_scale.x; gr.scales[3 * idx + 1] = d_scale.y; gr.scales[3 * idx + 2] = d_scale.z; }
+    if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
+    if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
+}
+
+void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
+                                const float* slots, const GradsK& gr, hipStream_t st) {
+    const int nb = (s.N + kBlock - 1) / kBlock;
+    if (nb > 0) hipLaunchKernelGGL(k_preprocess_backward, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+}
+
+}  // namespace sr

@@ -1,0 +1,257 @@
+// Alpha compositing (forward) and its replay (backward) for gfx950.
+//
+// Semantics: SURVEY.md Appendix A "Forward blend" / "Backward blend" -- the renderCUDA kernels of
+// the published rasterizer reached from reference gaussian_renderer/__init__.py:94-102, plus the
+// depth output of the pinned fork and an alpha (= 1 - final transmittance) output that makes the
+// reference's second "mask" pass (gaussian_renderer/__init__.py:104-115) unnecessary.
+//
+// MI355X mapping: one workgroup (4 wavefronts) per 16x16 binning tile; each 64-lane wavefront owns
+// one 8x8 sub-tile.  A batch of the tile's sorted list is staged once in LDS by all 256 threads
+// (coalesced id loads + 48-byte record gathers), then every wavefront compacts -- with one ballot per
+// 64 entries -- the indices of the splats whose alpha >= 1/255 support box reaches *its* 8x8 pixels
+// and blends only those, reading records back with LDS broadcast reads.  Early termination is per
+// wavefront.  The backward pass reduces the per-pixel gradient contributions with DPP wave
+// reductions, combines the 4 wavefronts through LDS in a fixed order and writes ONE record per
+// tile-splat instance to a scratch slot: no floating-point atomics anywhere, bit-reproducible.
+#include "kernels.h"
+
+namespace sr {
+
+constexpr int kFwdBatch = 256;
+constexpr int kBwdBatch = 128;
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const Geom g, const Binning b, const Image im,
+                                                           float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                           float* __restrict__ out_alpha) {
+    __shared__ float4 s_r0[kFwdBatch];
+    __shared__ float4 s_r1[kFwdBatch];
+    __shared__ float4 s_r2[kFwdBatch];
+    __shared__ uint16_t s_list[4][kFwdBatch];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % v.gx, ty = tile / v.gx;
+    const int wave = wave_id(), lane = lane_id();
+    const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
+    const int px = sx + (lane & 7), py = sy + (lane >> 3);
+    const bool inside = px < v.W && py < v.H;
+    const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
+    const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
+    const uint64_t lt = lanemask_lt();
+
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = start; base < end; base += kFwdBatch) {
+        if (__syncthreads_count(done) == kBlock) break;  // also fences LDS reuse
+        const uint32_t i = base + threadIdx.x;
+        if (i < end) {
+            const uint32_t id = b.sorted_id[i];
+            s_r0[threadIdx.x] = g.rec0[id];
+            s_r1[threadIdx.x] = g.rec1[id];
+            s_r2[threadIdx.x] = g.rec2[id];
+        }
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
+        if (__ballot(!done) != 0ull) {
+            int m = 0;
+            for (int c = 0; c < cnt; c += kWave) {
+                const int e = c + lane;
+                const bool ok = e < cnt && subtile_overlap(s_r0[e < cnt ? e : 0], sxf, syf);
+                const uint64_t mask = __ballot(ok);
+                if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
+                m += __popcll(mask);
+            }
+            wave_lds_fence();
+            for (int k = 0; k < m; ++k) {
+                const int e = s_list[wave][k];
+                const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+                if (!done) {
+                    float G, alpha;
+                    if (pair_alpha(r0.x - pxf, r0.y - pyf, r1, G, alpha)) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < kTStop) {
+                            done = true;
+                        } else {
+                            const float w = alpha * T;
+                            Cr += r2.x * w; Cg += r2.y * w; Cb += r2.z * w; D += r2.w * w;
+                            T = test_T;
+                            last = (base - start) + (uint32_t)e + 1u;
+                        }
+                    }
+                }
+                if ((k & 7) == 7 && __ballot(!done) == 0ull) break;
+            }
+        }
+    }
+    if (inside) {
+        const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
+        out_color[pix] = Cr + T * v.bg[0];
+        out_color[hw + pix] = Cg + T * v.bg[1];
+        out_color[2 * hw + pix] = Cb + T * v.bg[2];
+        out_depth[pix] = D;
+        if (out_alpha) out_alpha[pix] = 1.0f - T;
+        im.final_T[pix] = T;
+        im.n_contrib[pix] = last;
+    }
+}
+
+void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+                           float* out_color, float* out_depth, float* out_alpha, hipStream_t st) {
+    const int tiles = v.gx * v.gy;
+    if (tiles > 0) hipLaunchKernelGGL(k_render_forward, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, out_color, out_depth, out_alpha);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const Geom g, const Binning b, const Image im,
+                                                            const float* __restrict__ dL_dcolor,
+                                                            const float* __restrict__ dL_ddepth,
+                                                            const float* __restrict__ dL_dalpha,
+                                                            float* __restrict__ slots) {
+    __shared__ float4 s_r0[kBwdBatch];
+    __shared__ float4 s_r1[kBwdBatch];
+    __shared__ float4 s_r2[kBwdBatch];
+    __shared__ uint32_t s_inst[kBwdBatch];
+    __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
+    __shared__ uint16_t s_list[4][kBwdBatch];
+    __shared__ uint32_t s_max[4];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % v.gx, ty = tile / v.gx;
+    const int wave = wave_id(), lane = lane_id();
+    const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
+    const int px = sx + (lane & 7), py = sy + (lane >> 3);
+    const bool inside = px < v.W && py < v.H;
+    const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
+    const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
+    const int n = (int)(end - start);
+    const uint64_t lt = lanemask_lt();
+    const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
+
+    int my_last = 0;
+    float T_final = 0.f, gR = 0.f, gG = 0.f, gB = 0.f, gD = 0.f, gA = 0.f;
+    if (inside) {
+        my_last = (int)im.n_contrib[pix];
+        T_final = im.final_T[pix];
+        gR = dL_dcolor[pix]; gG = dL_dcolor[hw + pix]; gB = dL_dcolor[2 * hw + pix];
+        if (dL_ddepth) gD = dL_ddepth[pix];
+        if (dL_dalpha) gA = dL_dalpha[pix];
+    }
+    const float bg_dot = v.bg[0] * gR + v.bg[1] * gG + v.bg[2] * gB;
+
+    int wmax = my_last;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    if (lane == 0) s_max[wave] = (uint32_t)wmax;
+    __syncthreads();
+    const int bmax = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+
+    float4* slot4 = reinterpret_cast<float4*>(slots);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // list entries behind every pixel's last contributor receive no gradient
+    for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
+        const size_t inst = b.sorted_inst[start + i];
+        slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
+    }
+
+    float T = T_final;
+    float acR = 0.f, acG = 0.f, acB = 0.f, acD = 0.f, acA = 0.f;       // colour accumulated behind
+    float last_alpha = 0.f, lR = 0.f, lG = 0.f, lB = 0.f, lD = 0.f;
+
+    for (int top = bmax; top > 0; top -= kBwdBatch) {
+        const int cnt = min(kBwdBatch, top);
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t pos = start + (uint32_t)(top - 1 - (int)threadIdx.x);
+            const uint32_t id = b.sorted_id[pos];
+            s_r0[threadIdx.x] = g.rec0[id];
+            s_r1[threadIdx.x] = g.rec1[id];
+            s_r2[threadIdx.x] = g.rec2[id];
+            s_inst[threadIdx.x] = b.sorted_inst[pos];
+        }
+        {
+            float4* acc = &s_acc[0][0][0];
+            for (int i = threadIdx.x; i < 4 * kBwdBatch * (kSlotFloats / 4); i += kBlock) acc[i] = zero4;
+        }
+        __syncthreads();
+        if (wmax > top - cnt) {
+            int m = 0;
+            for (int c = 0; c < cnt; c += kWave) {
+                const int e = c + lane;
+                const bool ok = e < cnt && (top - 1 - e) < wmax && subtile_overlap(s_r0[e < cnt ? e : 0], sxf, syf);
+                const uint64_t mask = __ballot(ok);
+                if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
+                m += __popcll(mask);
+            }
+            wave_lds_fence();
+            for (int k = 0; k < m; ++k) {
+                const int e = s_list[wave][k];
+                const int pos = top - 1 - e;
+                const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+                const float dx = r0.x - pxf, dy = r0.y - pyf;
+                float G = 0.f, alpha = 0.f;
+                bool contrib = false;
+                if (pos < my_last) contrib = pair_alpha(dx, dy, r1, G, alpha);
+                if (__ballot(contrib) == 0ull) continue;
+                float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dd = 0.f;
+                if (contrib) {
+                    T = T / (1.0f - alpha);
+                    const float wgt = alpha * T;
+                    const float keep = 1.0f - last_alpha;
+                    acR = last_alpha * lR + keep * acR; lR = r2.x;
+                    acG = last_alpha * lG + keep * acG; lG = r2.y;
+                    acB = last_alpha * lB + keep * acB; lB = r2.z;
+                    acD = last_alpha * lD + keep * acD; lD = r2.w;
+                    acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
+                    float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r2.w - acD) * gD + (1.0f - acA) * gA;
+                    dLa *= T;
+                    last_alpha = alpha;
+                    dLa += (-T_final / (1.0f - alpha)) * bg_dot;
+                    const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
+                    S0 = g1; Sx = g1 * dx; Sy = g1 * dy; Sxx = Sx * dx; Sxy = Sx * dy; Syy = Sy * dy;
+                    dr = wgt * gR; dg = wgt * gG; db = wgt * gB; dd = wgt * gD;
+                }
+                S0 = wave_sum_to_lane63(S0); Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
+                Sxx = wave_sum_to_lane63(Sxx); Sxy = wave_sum_to_lane63(Sxy); Syy = wave_sum_to_lane63(Syy);
+                dr = wave_sum_to_lane63(dr); dg = wave_sum_to_lane63(dg); db = wave_sum_to_lane63(db);
+                dd = wave_sum_to_lane63(dd);
+                if (lane == 63) {
+                    s_acc[wave][e][0] = make_float4(S0, Sx, Sy, Sxx);
+                    s_acc[wave][e][1] = make_float4(Sxy, Syy, dr, dg);
+                    s_acc[wave][e][2] = make_float4(db, dd, 0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const int e = threadIdx.x;
+            const size_t inst = s_inst[e];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 a0 = s_acc[0][e][q], a1 = s_acc[1][e][q], a2 = s_acc[2][e][q], a3 = s_acc[3][e][q];
+                slot4[inst * 3 + q] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                                  (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+                            const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                            float* slots, hipStream_t st) {
+    const int tiles = v.gx * v.gy;
+    if (tiles > 0) hipLaunchKernelGGL(k_render_backward, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+}
+
+}  // namespace sr

@@ -1,0 +1,228 @@
+"""Python facade of the MI355X splat rasterizer.
+
+Mirrors the interface of the pip dependency SplatFields imports at reference
+gaussian_renderer/__init__.py:14 (``diff_gaussian_rasterization``, pinned in reference
+README.md:28): ``GaussianRasterizationSettings`` (the 12 keyword fields built at
+gaussian_renderer/__init__.py:59-72) and ``GaussianRasterizer`` (an ``nn.Module`` whose
+``forward`` is called at gaussian_renderer/__init__.py:94-102 / :106-114 and returns
+``(color[3,H,W], radii[N] int32, depth[1,H,W])``), with the same argument names, the same
+"exactly one of" validation messages and gradients for
+``means3D, means2D, shs | colors_precomp, opacities, scales, rotations | cov3D_precomp``.
+
+Everything below the facade goes through the C ABI of ``libsplatraster.so``
+(include/splatraster.h) with raw device pointers; PyTorch only owns memory and streams.
+There is no CPU path: tensors must live on a HIP device and the library must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    """fp32, on `device`, contiguous -- the camera tensors arrive strided (scene/cameras.py:68,74)."""
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _opt(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if (t is None or t.numel() == 0) else t
+
+
+class _ViewPack:
+    """Keeps the contiguous camera tensors alive next to the C struct that points at them."""
+
+    def __init__(self, rs: GaussianRasterizationSettings, device, sh_coeffs: int):
+        self.viewmatrix = _f32c(rs.viewmatrix, device).reshape(-1)
+        self.projmatrix = _f32c(rs.projmatrix, device).reshape(-1)
+        self.campos = _f32c(rs.campos, device).reshape(-1)
+        self.bg = _f32c(rs.bg, device).reshape(-1)
+        if self.viewmatrix.numel() != 16 or self.projmatrix.numel() != 16:
+            raise RuntimeError("viewmatrix and projmatrix must hold 16 elements ([4,4] or [1,4,4])")
+        if self.campos.numel() != 3 or self.bg.numel() != 3:
+            raise RuntimeError("campos and bg must hold 3 elements")
+        self.struct = _lib.SrView(
+            int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+            float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), int(bool(rs.prefiltered)),
+            int(bool(rs.debug)), self.viewmatrix.data_ptr(), self.projmatrix.data_ptr(),
+            self.campos.data_ptr(), self.bg.data_ptr())
+
+
+def _splats_struct(n, means3D, opacities, scales, rotations, cov3D, shs, colors) -> _lib.SrSplats:
+    g = lambda t: None if t is None else t.data_ptr()
+    return _lib.SrSplats(int(n), g(means3D), g(opacities), g(scales), g(rotations), g(cov3D), g(shs), g(colors))
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Autograd bridge; the counterpart of [EXT] ``_RasterizeGaussians``."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings: GaussianRasterizationSettings):
+        lib = _lib.load()
+        if not means3D.is_cuda:
+            raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
+        dev = means3D.device
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        n = means3D.shape[0]
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        means3D_c, opac_c = f(means3D), f(opacities).reshape(-1)
+        sh_c, col_c, sc_c, rot_c, cov_c = f(_opt(sh)), f(_opt(colors_precomp)), f(_opt(scales)), f(_opt(rotations)), f(_opt(cov3Ds_precomp))
+        if opac_c.numel() != n:
+            raise RuntimeError("opacities must have dimensions (num_points, 1)")
+        for name, t, last in (("shs", sh_c, None), ("colors_precomp", col_c, 3), ("scales", sc_c, 3),
+                              ("rotations", rot_c, 4), ("cov3D_precomp", cov_c, 6)):
+            if t is not None and (t.shape[0] != n or (last is not None and t.shape[-1] != last)):
+                raise RuntimeError(f"{name} has an unexpected shape {tuple(t.shape)} for {n} points")
+        if sh_c is not None and (sh_c.dim() != 3 or sh_c.shape[2] != 3):
+            raise RuntimeError("shs must have dimensions (num_points, K, 3)")
+        sh_coeffs = 0 if sh_c is None else int(sh_c.shape[1])
+
+        view = _ViewPack(raster_settings, dev, sh_coeffs)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.zeros(n, dtype=torch.int32, device=dev)
+        ctx.raster_settings = raster_settings
+        ctx.sh_coeffs = sh_coeffs
+        ctx.n = n
+        ctx.opac_shape = tuple(opacities.shape)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        if n == 0:
+            color[:] = view.bg.reshape(3, 1, 1)
+            depth.zero_()
+            alpha.zero_()
+            ctx.instances = 0
+            ctx.save_for_backward()
+            return color, radii, depth, alpha
+
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            splats = _splats_struct(n, means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c)
+            geom = torch.empty(lib.sr_geom_bytes(n, H, W), dtype=torch.uint8, device=dev)
+            image = torch.empty(lib.sr_image_bytes(H, W), dtype=torch.uint8, device=dev)
+            inst = C.c_longlong(0)
+            _lib.check(lib.sr_forward_prepare(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii),
+                                              C.byref(inst), stream))
+            instances = int(inst.value)
+            binning = torch.empty(lib.sr_binning_bytes(instances, H, W), dtype=torch.uint8, device=dev)
+            _lib.check(lib.sr_forward_render(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning),
+                                             instances, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), stream))
+        ctx.instances = instances
+        ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        n = ctx.n
+        if n == 0:
+            return (None,) * 9
+        lib = _lib.load()
+        means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image = ctx.saved_tensors
+        dev = means3D.device
+        H, W = int(rs.image_height), int(rs.image_width)
+        g = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        grad_color = g(grad_color)
+        if grad_color is None:
+            grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        grad_depth, grad_alpha = g(grad_depth), g(grad_alpha)
+        view = _ViewPack(rs, dev, ctx.sh_coeffs)
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        d_means3D, d_means2D, d_opac = new(n, 3), new(n, 3), new(n, 1)
+        d_sc = new(n, 3) if sc is not None else None
+        d_rot = new(n, 4) if rot is not None else None
+        d_cov = new(n, 6) if cov is not None else None
+        d_sh = new(*sh.shape) if sh is not None else None
+        d_col = new(n, 3) if col is not None else None
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col)
+            scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.instances), dtype=torch.uint8, device=dev)
+            p = lambda t: None if t is None else t.data_ptr()
+            grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col))
+            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.instances,
+                                       _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
+                                       _ptr(scratch), C.byref(grads), stream))
+        # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings
+        return d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    """Returns (color, radii, depth, alpha).  ``alpha`` (= 1 - final transmittance) is the fused equivalent of
+    the reference's second rasterization with white colours on a black background
+    (gaussian_renderer/__init__.py:104-115)."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Near-plane visibility mask ([EXT] ``GaussianRasterizer.markVisible``)."""
+        lib = _lib.load()
+        if not positions.is_cuda:
+            raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
+        with torch.no_grad():
+            rs = self.raster_settings
+            dev = positions.device
+            pos = positions.detach().to(torch.float32).contiguous()
+            vm, pj = _f32c(rs.viewmatrix, dev), _f32c(rs.projmatrix, dev)
+            present = torch.zeros(pos.shape[0], dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sr_mark_visible(pos.shape[0], _ptr(pos), _ptr(vm), _ptr(pj), _ptr(present), _stream_ptr(dev)))
+        return present.bool()
+
+    def _check(self, shs, colors_precomp, scales, rotations, cov3D_precomp):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+    def forward_ex(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                   cov3D_precomp=None):
+        """Same as ``forward`` plus the fused alpha image: (color, radii, depth, alpha)."""
+        self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        color, radii, depth, _ = self.forward_ex(means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
+                                                 cov3D_precomp)
+        return color, radii, depth

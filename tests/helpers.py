@@ -1,0 +1,82 @@
+"""Shared helpers of the parity tests: scene construction, HIP invocation through the facade
+(-> C ABI), and tolerance-aware comparison against the oracle."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from oracle import torch_oracle as O
+from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+
+GRAD_NAMES_SH = ["means3D", "scales", "rotations", "opacities", "shs", "means2D"]
+
+
+def make_scene(n, width, height, *, seed=1234, view=1, sh_degree=3, bg=(1.0, 1.0, 1.0), mean_scale=None,
+               scale_modifier=1.0):
+    sp = make_splats(n, seed=seed, mean_scale=mean_scale)
+    cam = make_camera(view, width, height)
+    st = O.settings_from_camera(cam, torch.tensor(bg, dtype=torch.float32), sh_degree, scale_modifier)
+    gi, gd, ga = make_upstream_grads(height, width)
+    return sp, cam, st, (gi, gd, ga)
+
+
+def run_hip(sp, st, grads, device, *, use_sh=True, with_depth=True, with_alpha=True):
+    """Forward + backward through the drop-in facade on `device`.  Returns (outputs dict, grads dict) on CPU."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    gi, gd, ga = [g.to(device) for g in grads]
+    leaf = {k: v.detach().to(device).clone().requires_grad_(True) for k, v in sp.items()}
+    means2D = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    rs = GaussianRasterizationSettings(
+        image_height=st.image_height, image_width=st.image_width, tanfovx=st.tanfovx, tanfovy=st.tanfovy,
+        bg=st.bg.to(device), scale_modifier=st.scale_modifier, viewmatrix=st.viewmatrix.to(device),
+        projmatrix=st.projmatrix.to(device), sh_degree=st.sh_degree, campos=st.campos.to(device),
+        prefiltered=False, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    color, radii, depth, alpha = rast.forward_ex(
+        means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
+        shs=leaf["shs"] if use_sh else None, colors_precomp=None if use_sh else leaf["colors_precomp"],
+        scales=leaf["scales"], rotations=leaf["rotations"])
+    loss = (color * gi).sum()
+    if with_depth:
+        loss = loss + (depth * gd).sum()
+    if with_alpha:
+        loss = loss + (alpha * ga).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
+    g = {k: leaf[k].grad.detach().cpu() for k in names}
+    g["means2D"] = means2D.grad.detach().cpu()
+    out = dict(color=color.detach().cpu(), radii=radii.cpu(), depth=depth.detach().cpu(), alpha=alpha.detach().cpu())
+    return out, g
+
+
+def image_errors(hip: torch.Tensor, ref: torch.Tensor, fragile: torch.Tensor, floor: float = 1e-3):
+    """max relative error on robust pixels (relative to max(|ref|, floor), SURVEY.md Appendix A
+    "Tolerance basis") and max absolute error on threshold-fragile pixels."""
+    ref = ref.to(torch.float64)
+    err = (hip.to(torch.float64) - ref).abs()
+    rel = err / ref.abs().clamp_min(floor)
+    frag = fragile[None].expand_as(ref)
+    robust = rel[~frag].max().item() if (~frag).any() else 0.0
+    fr = err[frag].max().item() if frag.any() else 0.0
+    return robust, fr
+
+
+def grad_error(hip: torch.Tensor, ref: torch.Tensor):
+    """max |hip - ref| relative to max |ref| of the tensor."""
+    ref = ref.to(torch.float64)
+    scale = ref.abs().max().clamp_min(1e-30)
+    return ((hip.to(torch.float64) - ref).abs().max() / scale).item()
+
+
+def radii_mismatch(hip_radii, pre, tol=2e-3):
+    """number of radii that differ although 3*sqrt(lambda) is not within `tol` of an integer
+    and the visibility decision is not marginal."""
+    ref = pre.radii
+    diff = hip_radii.to(torch.int64) != ref.to(torch.int64)
+    raw = pre.radius_raw.to(torch.float64)
+    near_int = (raw - raw.round()).abs() < tol * raw.clamp_min(1.0)
+    near_cull = (pre.depth.to(torch.float64) - 0.2).abs() < 1e-5
+    # marginal tile-rect emptiness: bounding square touches the tile grid edge within tol
+    return int((diff & ~near_int & ~near_cull).sum())
