@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: forward+backward splat rasterization of one view per GPU.
+
+Contract (task statement §④): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver
+launches it with torch.distributed.run, one rank per GPU.  A *step* = each rank renders ONE view of
+the same splat cloud (forward + backward through the drop-in facade -> C ABI -> HIP kernels) and,
+for N>1, the per-splat gradients are sum-all-reduced over RCCL (view-parallel training step,
+reference train.py:169-252).  Per-GPU work is fixed as N grows ("weak" scaling).
+
+metric  = splats*px rasterized per second (fwd+bwd) = n_gpus * N_splats * H * W / t_step
+workload = BASELINE.json's metric configuration: 1 M synthetic splats, 800x800, SH degree 3.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:35 (6.29e12 measured-achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--splats", type=int, default=1_000_000)
+    p.add_argument("--width", type=int, default=800)
+    p.add_argument("--height", type=int, default=800)
+    p.add_argument("--color", choices=["sh", "precomp"], default="sh")
+    p.add_argument("--sh-degree", type=int, default=3)
+    p.add_argument("--cpu-baseline", choices=["auto", "none"], default="auto")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded baseline sample")
+    return p.parse_args()
+
+
+def stage_bytes(stage: str, n: int, vis: float, R: float, hw: int, c_in: int) -> float:
+    """Algorithmic HBM bytes of one launch of a pipeline stage (SURVEY.md Appendix C terms)."""
+    return {
+        # read mean 12 + scale 12 + rot 16 + opacity 4 + colour input; write radii 4; visible: 40 B state
+        "preprocess": n * (44 + c_in + 4) + vis * 40,
+        "scan": n / 256 * 8,
+        # read depth/rect/count per splat, write key 8 + value 4 per instance
+        "emit": n * 16 + R * 12,
+        # read key/value 12, write sorted id 4 + instance 4
+        "sort_tiles": R * 20,
+        # read id 4 + gather 40 B state per instance; write rgb 12, depth 4, alpha 4, final_T 4, n_contrib 4 per pixel
+        "render_forward": R * 44 + hw * 28,
+        # read id 4 + slot index 4 + 40 B state, write 40 B gradient moments per instance;
+        # read dL/drgb 12, dL/ddepth 4, dL/dalpha 4, final_T 4, n_contrib 4 per pixel
+        "render_backward": R * 88 + hw * 28,
+        # re-read inputs, read 40 B per instance, write all gradients
+        "preprocess_backward": n * (44 + c_in) + R * 40 + vis * 40 + n * (12 + 12 + 12 + 16 + 4 + c_in),
+    }[stage]
+
+
+def pipeline_bytes(n: int, vis: float, R: float, hw: int, c_in: int) -> float:
+    """B_alg of SURVEY.md §8d: N*(3*(44+C_in)+16) + V_vis*160 + R*164 + H*W*48."""
+    return n * (3 * (44 + c_in) + 16) + vis * 160 + R * 164 + hw * 48
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from splatfields_amd import _lib, rasterizer as rz
+    from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    from splatfields_amd.view_parallel import allreduce_gradients
+    import math
+
+    lib = _lib.load()
+    N, H, W = args.splats, args.height, args.width
+    use_sh = args.color == "sh"
+    c_in = 12 * 16 if use_sh else 12
+    sp = make_splats(N, seed=1234, device=dev)
+    names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
+    params = {k: sp[k].clone().requires_grad_(True) for k in names}
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    bg = torch.ones(3, device=dev)
+    cams = [make_camera(k, W, H, device=dev) for k in range(8)]
+    stats = {"R": 0.0, "vis": 0.0, "n": 0}
+
+    def one_step(step_idx: int, record: bool = False):
+        cam = cams[(step_idx * world + rank) % len(cams)]
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+            bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+            sh_degree=args.sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+        for p in params.values():
+            p.grad = None
+        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+            shs=params["shs"] if use_sh else None, colors_precomp=None if use_sh else params["colors_precomp"],
+            scales=params["scales"], rotations=params["rotations"])
+        loss = (color * gi).sum() + (depth * gd).sum() + (alpha * ga).sum()
+        loss.backward()
+        if world > 1:
+            allreduce_gradients(list(params.values()), world)
+        if record:
+            stats["R"] += rz.LAST_INSTANCES
+            stats["vis"] += float((radii > 0).sum().item())
+            stats["n"] += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * N * H * W * args.steps / elapsed
+
+    # ---- per-stage durations with HIP events on the launch stream (same steps, same inputs) ----
+    lib.sr_profile_enable(1)
+    for i in range(args.steps):
+        one_step(args.warmup + i, record=True)
+    torch.cuda.synchronize()
+    ms = (C.c_double * _lib.PROFILE_STAGES)()
+    cnt = (C.c_longlong * _lib.PROFILE_STAGES)()
+    lib.sr_profile_collect(ms, cnt)
+    lib.sr_profile_enable(0)
+    stage_ms = {lib.sr_profile_stage_name(i).decode(): (ms[i] / max(cnt[i], 1)) for i in range(_lib.PROFILE_STAGES)}
+    R = stats["R"] / max(stats["n"], 1)
+    vis = stats["vis"] / max(stats["n"], 1)
+    dom = max(stage_ms, key=stage_ms.get)
+    dom_bytes = stage_bytes(dom, N, vis, R, H * W, c_in)
+    dom_bw = dom_bytes / (stage_ms[dom] * 1e-3)
+    b_alg = pipeline_bytes(N, vis, R, H * W, c_in)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "splats*px rasterized/sec (fwd+bwd)", "value": value, "unit": "splat*px/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
+                               f"1 view per GPU per step, colour+depth+alpha outputs, fwd+bwd"
+                               + (", RCCL sum all-reduce of per-splat gradients" if world > 1 else ""),
+                   "splats": N, "width": W, "height": H, "views_per_step": world,
+                   "visible_splats": vis, "tile_instances": R},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": dom_bw / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                     "avg_launch_ms": stage_ms[dom]},
+        "roofline_pipeline": {"b_alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                              "frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
+                              "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
+        "stage_ms": stage_ms,
+    }
+    if rank == 0 and world == 1 and args.cpu_baseline != "none":
+        from oracle.cpu_baseline import run_cpu_baseline  # the oracle is used here only as the timed CPU baseline
+        out["cpu_baseline"] = run_cpu_baseline(N, H, W, use_sh, args.sh_degree, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -118,6 +118,15 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, unsigned char* present, void* hip_stream);
 
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * live roofline figure; off by default, adds two event records per launch when on).
+ * sr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch counts
+ * per stage into the caller's arrays of SR_PROFILE_STAGES entries, and clears the recording. */
+#define SR_PROFILE_STAGES 7 /* preprocess, scan, emit, sort_tiles, render_forward, render_backward, preprocess_backward */
+int sr_profile_enable(int on);
+int sr_profile_collect(double* ms_sum, long long* launches);
+const char* sr_profile_stage_name(int stage);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "kernels.h"
 
 namespace {
@@ -14,6 +15,24 @@ int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     return fail(std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// ---- optional per-stage timing (HIP events on the launch stream) ----
+struct ProfRec { int stage; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+const char* kStageNames[SR_PROFILE_STAGES] = {"preprocess", "scan", "emit", "sort_tiles", "render_forward",
+                                              "render_backward", "preprocess_backward"};
+struct StageTimer {
+    int idx = -1; hipStream_t st;
+    StageTimer(int stage, hipStream_t s) : st(s) {
+        if (!g_prof_on) return;
+        ProfRec r; r.stage = stage;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        hipEventRecord(r.a, st);
+        g_prof.push_back(r); idx = (int)g_prof.size() - 1;
+    }
+    ~StageTimer() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
+};
 
 #define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
@@ -83,9 +102,9 @@ int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, i
     sr::Geom g;
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     const int nb = (s.N + sr::kBlock - 1) / sr::kBlock;
-    sr::launch_preprocess(v, s, g, radii, st);
+    { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
     SR_TRY(after_launch(view, st, "preprocess"));
-    sr::launch_scan_small(g, nb, v.gx * v.gy, st);
+    { StageTimer t_(1, st); sr::launch_scan_small(g, nb, v.gx * v.gy, st); }
     SR_TRY(after_launch(view, st, "scan"));
     uint32_t total = 0;
     SR_TRY(check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
@@ -107,11 +126,11 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     sr::carve_binning(binning, instances, &b);
     sr::carve_image(image, v.H, v.W, &im);
-    sr::launch_emit(v, s.N, g, b, st);
+    { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
     SR_TRY(after_launch(view, st, "emit"));
-    sr::launch_sort_tiles(v, g, b, st);
+    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, st); }
     SR_TRY(after_launch(view, st, "sort_tiles"));
-    sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st);
+    { StageTimer t_(4, st); sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st); }
     SR_TRY(after_launch(view, st, "render_forward"));
     return 0;
 }
@@ -135,14 +154,14 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     sr::carve_binning(const_cast<void*>(binning), instances, &b);
     sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
     float* slots = static_cast<float*>(scratch);
-    sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
+    { StageTimer t_(5, st); sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st); }
     SR_TRY(after_launch(view, st, "render_backward"));
     sr::GradsK gr;
     gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
     gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
     gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
     gr.shs = s.shs ? grads->dL_dshs : nullptr; gr.colors = s.colors ? grads->dL_dcolors : nullptr;
-    sr::launch_preprocess_backward(v, s, g, radii, slots, gr, st);
+    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, gr, st); }
     SR_TRY(after_launch(view, st, "preprocess_backward"));
     return 0;
 }
@@ -153,5 +172,22 @@ int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const 
     sr::launch_mark_visible(n, means3D, viewmatrix, present, st);
     return check_hip(hipGetLastError(), "mark_visible");
 }
+
+int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+
+int sr_profile_collect(double* ms_sum, long long* launches) {
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            if (ms_sum) ms_sum[r.stage] += ms;
+            if (launches) launches[r.stage] += 1;
+        }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+const char* sr_profile_stage_name(int stage) { return (stage >= 0 && stage < SR_PROFILE_STAGES) ? kStageNames[stage] : ""; }
 
 }  // extern "C"

@@ -39,6 +39,9 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+LAST_INSTANCES = 0  # tile-splat instances of the most recent forward (diagnostics / bench)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -138,6 +141,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             binning = torch.empty(lib.sr_binning_bytes(instances, H, W), dtype=torch.uint8, device=dev)
             _lib.check(lib.sr_forward_render(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning),
                                              instances, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), stream))
+        global LAST_INSTANCES
+        LAST_INSTANCES = instances
         ctx.instances = instances
         ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image)
         return color, radii, depth, alpha
