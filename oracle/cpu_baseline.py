@@ -1,0 +1,44 @@
+"""bench.py's `cpu_baseline` leg: the C oracle (kind "port") timed on the host cores of the GPU box.
+TEST/MEASUREMENT INFRASTRUCTURE ONLY -- it is a reported baseline, never the product path."""
+from __future__ import annotations
+
+import math
+import os
+import time
+
+import torch
+
+
+def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_degree: int, target_seconds: float):
+    from oracle import c_oracle
+    from oracle import torch_oracle as O
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    cores = os.cpu_count() or 1
+    sp = make_splats(n_splats, seed=1234)
+    cam = make_camera(0, width, height)
+    st = O.settings_from_camera(cam, torch.ones(3), sh_degree)
+    gi, gd, ga = make_upstream_grads(height, width)
+    gx, gy = (width + 15) // 16, (height + 15) // 16
+
+    def timed(window):
+        t0 = time.perf_counter()
+        c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=gi, g_depth=gd, g_alpha=ga, tile_window=window, threads=cores)
+        return time.perf_counter() - t0
+
+    # calibrate on a centred crop of tile rows, then take the largest crop that fits the time budget:
+    # every splat is always preprocessed and binned; only the blended tile window is bounded.
+    rows = max(1, gy // 16)
+    y0 = (gy - rows) // 2
+    t_small = timed((0, y0, gx, y0 + rows))
+    scale = max(1.0, target_seconds / max(t_small, 1e-3))
+    rows_full = int(min(gy, max(rows, math.floor(rows * scale * 0.8))))
+    y0 = (gy - rows_full) // 2
+    window = (0, y0, gx, y0 + rows_full)
+    t = timed(window)
+    px = min(height, (y0 + rows_full) * 16) - y0 * 16
+    frac = rows_full / gy
+    return {"value": n_splats * px * width / t, "unit": "splat*px/s", "cores": cores, "kind": "port",
+            "seconds": t,
+            "sample": f"C oracle (oracle/raster_ref.c, OpenMP {cores} threads), fwd+bwd of view 0 of the same workload: "
+                      f"all {n_splats} splats preprocessed and binned, tile rows {y0}..{y0 + rows_full} of {gy} "
+                      f"({frac:.0%} of the image, {px}x{width} px) blended and back-propagated"}

@@ -198,7 +198,7 @@ def preprocess(means3D, means2D, opacities, shs, colors_precomp, scales, rotatio
     rect = torch.nan_to_num(rect, nan=0.0).to(torch.int64)
     visible = visible & (((rect[:, 2] - rect[:, 0]) * (rect[:, 3] - rect[:, 1])) > 0)
 
-    if colors_precomp is not None and colors_precomp.numel() > 0:
+    if shs is None or shs.numel() == 0:
         rgb = colors_precomp
     else:
         rgb = sh_to_rgb(int(s.sh_degree), shs, means3D, campos)

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/.  Run ONLY in the build container, where the
+reference checkout exists at /root/reference; the fixtures (pure numbers) are what travels.
+
+  ref_pieces.npz   -- outputs of the reference's own in-tree restatements of rasterizer math, computed by
+                      importing them: utils/sh_utils.py:57 eval_sh, utils/graphics_utils.py:42,56
+                      getWorld2View2 / getProjectionMatrix, scene/cameras.py:68-74 matrix assembly (redone with
+                      the imported helpers), utils/general_utils.py:138-171 rotation / covariance builders
+                      (device="cuda" literals patched to CPU), extract_geo.py:40-44 colour rule.
+  render_contract.json -- the call pattern of gaussian_renderer/__init__.py:30-124 captured with a recording
+                      stand-in for diff_gaussian_rasterization (argument names, shapes, dtypes, bg of the
+                      second pass, output dict keys / shapes / dtypes).
+  tiny_*.npz       -- small scenes: inputs + fp64 torch-oracle outputs and gradients (regression pins for both
+                      oracles and for the HIP path).
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name in ["trimesh", "cv2", "plyfile", "imageio", "simple_knn", "simple_knn._C", "lpips", "torchvision",
+                 "mmgen", "mmgen.models", "mmgen.models.builder", "mmgen.models.architectures",
+                 "mmgen.models.architectures.common", "mmcv", "mmcv.cnn", "mmcv.runner", "diffusers",
+                 "diffusers.models", "diffusers.models.resnet", "diffusers.models.attention", "sklearn.neighbors"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.__dict__.setdefault("__path__", [])
+                sys.modules[name] = m
+    sys.modules["plyfile"].PlyData = object
+    sys.modules["plyfile"].PlyElement = object
+    sys.modules["simple_knn._C"].distCUDA2 = lambda *a, **k: None
+
+
+def ref_pieces():
+    import_reference()
+    from utils import sh_utils, graphics_utils
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    # --- SH ---
+    n = 64
+    dirs = torch.randn(n, 3, generator=g, dtype=torch.float64)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    sh = torch.randn(n, 16, 3, generator=g, dtype=torch.float64)
+    out["sh_dirs"], out["sh_coeffs"] = dirs.numpy(), sh.numpy()
+    for deg in range(4):
+        # reference layout: [..., C, (deg+1)^2] (extract_geo.py:40 transposes features [N,16,3] -> [N,3,16])
+        out[f"sh_eval_deg{deg}"] = sh_utils.eval_sh(deg, sh.transpose(1, 2), dirs).numpy()
+    out["rgb2sh"] = sh_utils.RGB2SH(torch.linspace(0, 1, 5, dtype=torch.float64)).numpy()
+    # --- camera matrices ---
+    Rs, Ts, W2V, PRJ, FULL, CEN = [], [], [], [], [], []
+    for k in range(4):
+        q = torch.randn(4, generator=g, dtype=torch.float64)
+        q = q / q.norm()
+        r, x, y, z = q.tolist()
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                      [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                      [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+        T = torch.randn(3, generator=g, dtype=torch.float64).numpy()
+        fovx, fovy = 0.5 + 0.1 * k, 0.4 + 0.07 * k
+        w2v = torch.tensor(graphics_utils.getWorld2View2(R, T)).transpose(0, 1)       # scene/cameras.py:68
+        prj = graphics_utils.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)  # :70
+        full = (w2v.unsqueeze(0).bmm(prj.unsqueeze(0))).squeeze(0)                    # :72-73
+        cen = w2v.inverse()[3, :3]                                                    # :74
+        Rs.append(R); Ts.append(T); W2V.append(w2v.numpy()); PRJ.append(prj.numpy()); FULL.append(full.numpy()); CEN.append(cen.numpy())
+    out.update(cam_R=np.stack(Rs), cam_T=np.stack(Ts), cam_fov=np.array([[0.5 + 0.1 * k, 0.4 + 0.07 * k] for k in range(4)]),
+               cam_world_view=np.stack(W2V), cam_proj=np.stack(PRJ), cam_full=np.stack(FULL), cam_center=np.stack(CEN))
+    # --- rotation / covariance builders (device literals patched to CPU) ---
+    orig_zeros = torch.zeros
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return orig_zeros(*a, **k)
+    torch.zeros = zeros_cpu
+    try:
+        from utils import general_utils
+        q = torch.randn(32, 4, generator=g)
+        s = torch.rand(32, 3, generator=g) + 0.1
+        Rm = general_utils.build_rotation(q)  # normalises internally
+        L = general_utils.build_scaling_rotation(s, q)
+        cov = L @ L.transpose(1, 2)
+        out.update(quat=q.numpy(), quat_scales=s.numpy(), quat_rot=Rm.numpy(),
+                   cov6=general_utils.strip_symmetric(cov).numpy())
+    finally:
+        torch.zeros = orig_zeros
+    # --- ndc2Pix (scene/dataset_readers.py:515-516) evaluated literally ---
+    vv = np.linspace(-1.2, 1.2, 9)
+    out["ndc_v"] = vv
+    out["ndc_pix_800"] = ((vv + 1.0) * 800 - 1.0) * 0.5
+    np.savez_compressed(os.path.join(HERE, "ref_pieces.npz"), **out)
+    print("ref_pieces.npz:", sorted(out))
+
+
+def render_contract():
+    import_reference()
+    calls = []
+
+    class Settings:  # records keyword construction (gaussian_renderer/__init__.py:59-72)
+        def __init__(self, **kw):
+            self.kw = kw
+
+    class Rasterizer:
+        def __init__(self, raster_settings):
+            self.rs = raster_settings
+
+        def __call__(self, **kw):
+            rec = {"settings": {k: (list(v.shape) if torch.is_tensor(v) else v) for k, v in self.rs.kw.items()},
+                   "bg": self.rs.kw["bg"].tolist(),
+                   "args": {k: (None if v is None else {"shape": list(v.shape), "dtype": str(v.dtype)}) for k, v in kw.items()}}
+            calls.append(rec)
+            n = kw["means3D"].shape[0]
+            H, W = self.rs.kw["image_height"], self.rs.kw["image_width"]
+            img = torch.zeros(3, H, W) + kw["means2D"].sum() * 0 + kw["means3D"].sum() * 0
+            return img, torch.ones(n, dtype=torch.int32), torch.zeros(1, H, W)
+
+    # gaussian_renderer imports scene.gaussian_model only for a type name (:15); the real package drags in
+    # mmgen/diffusers, so give it an empty stand-in for this capture
+    scene_stub = types.ModuleType("scene"); scene_stub.__path__ = []
+    gm_stub = types.ModuleType("scene.gaussian_model"); gm_stub.GaussianModel = object
+    saved_scene = {k: sys.modules.get(k) for k in ("scene", "scene.gaussian_model")}
+    sys.modules["scene"], sys.modules["scene.gaussian_model"] = scene_stub, gm_stub
+    stub = types.ModuleType("diff_gaussian_rasterization")
+    stub.GaussianRasterizationSettings = Settings
+    stub.GaussianRasterizer = Rasterizer
+    saved = sys.modules.get("diff_gaussian_rasterization")
+    sys.modules["diff_gaussian_rasterization"] = stub
+    orig_zl = torch.zeros_like
+    def zl(t, **k):
+        k.pop("device", None)
+        return orig_zl(t, **k)
+    torch.zeros_like = zl
+    try:
+        sys.modules.pop("gaussian_renderer", None)
+        import gaussian_renderer
+        from splatfields_amd.synthetic import make_camera, make_splats
+        sp = make_splats(50, seed=3)
+        cam = make_camera(1, 64, 48)
+        gd = {"means3D": sp["means3D"].requires_grad_(True), "active_sh_degree": 2, "gaussian_opacity": sp["opacities"],
+              "gaussian_features": sp["shs"], "gaussian_scales": sp["scales"], "gaussian_rotations": sp["rotations"]}
+        pipe = types.SimpleNamespace(debug=False)
+        out = gaussian_renderer.render(cam, gd, pipe, torch.tensor([1.0, 1.0, 1.0]))
+        out["render"].sum().backward()
+        contract = {"calls": calls,
+                    "outputs": {k: (None if v is None else {"shape": list(v.shape), "dtype": str(v.dtype)}) for k, v in out.items()},
+                    "viewspace_points_is_leaf": bool(out["viewspace_points"].is_leaf),
+                    "viewspace_points_grad_populated": out["viewspace_points"].grad is not None}
+    finally:
+        torch.zeros_like = orig_zl
+        sys.modules.pop("gaussian_renderer", None)
+        for k, m in saved_scene.items():
+            if m is not None:
+                sys.modules[k] = m
+            else:
+                sys.modules.pop(k, None)
+        if saved is not None:
+            sys.modules["diff_gaussian_rasterization"] = saved
+        else:
+            sys.modules.pop("diff_gaussian_rasterization", None)
+    json.dump(contract, open(os.path.join(HERE, "render_contract.json"), "w"), indent=1, sort_keys=True)
+    print("render_contract.json:", len(calls), "rasterizer calls")
+
+
+def tiny_scenes():
+    from oracle import torch_oracle as O
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    specs = {"tiny_sh3": dict(n=300, w=64, h=48, deg=3, use_sh=True, seed=11, bg=(1.0, 1.0, 1.0), mod=1.0, ms=0.06),
+             "tiny_rgb": dict(n=200, w=40, h=56, deg=0, use_sh=False, seed=12, bg=(0.0, 0.0, 0.0), mod=1.0, ms=0.08),
+             "tiny_sh1_mod": dict(n=150, w=33, h=47, deg=1, use_sh=True, seed=13, bg=(0.2, 0.5, 0.9), mod=0.7, ms=0.1)}
+    for name, s in specs.items():
+        sp = make_splats(s["n"], seed=s["seed"], mean_scale=s["ms"])
+        cam = make_camera(3, s["w"], s["h"])
+        st = O.settings_from_camera(cam, torch.tensor(s["bg"]), s["deg"], s["mod"])
+        gi, gd, ga = make_upstream_grads(s["h"], s["w"], seed=99)
+        out, gr = O.fwd_bwd(sp, st, gi, gd, ga, use_sh=s["use_sh"], dtype=torch.float64)
+        arrs = {f"in_{k}": v.numpy() for k, v in sp.items()}
+        arrs.update(viewmatrix=st.viewmatrix.contiguous().numpy(), projmatrix=st.projmatrix.contiguous().numpy(),
+                    campos=st.campos.contiguous().numpy(), bg=np.array(s["bg"], np.float32),
+                    meta=np.array([s["h"], s["w"], s["deg"], int(s["use_sh"])]), tanfov=np.array([st.tanfovx, st.tanfovy]),
+                    scale_modifier=np.array(s["mod"]), g_img=gi.numpy(), g_depth=gd.numpy(), g_alpha=ga.numpy(),
+                    out_color=out.color.detach().numpy(), out_depth=out.depth.detach().numpy(),
+                    out_alpha=out.alpha.detach().numpy(), out_radii=out.radii.numpy(), fragile=out.fragile.numpy(),
+                    num_rendered=np.array(out.num_rendered))
+        arrs.update({f"grad_{k}": v.numpy() for k, v in gr.items()})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        print(name, "R =", out.num_rendered, "fragile px =", int(out.fragile.sum()))
+
+
+if __name__ == "__main__":
+    ref_pieces()
+    render_contract()
+    tiny_scenes()

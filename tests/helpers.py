@@ -45,8 +45,9 @@ def run_hip(sp, st, grads, device, *, use_sh=True, with_depth=True, with_alpha=T
     loss.backward()
     torch.cuda.synchronize()
     names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
-    g = {k: leaf[k].grad.detach().cpu() for k in names}
-    g["means2D"] = means2D.grad.detach().cpu()
+    gz = lambda t: (torch.zeros_like(t) if t.grad is None else t.grad).detach().cpu()
+    g = {k: gz(leaf[k]) for k in names}
+    g["means2D"] = gz(means2D)
     out = dict(color=color.detach().cpu(), radii=radii.cpu(), depth=depth.detach().cpu(), alpha=alpha.detach().cpu())
     return out, g
 

@@ -1,0 +1,63 @@
+"""Size-independent properties at BASELINE.json's full size (1 M splats, 800x800), where the oracles are too
+slow for a whole-image comparison: determinism, linearity of the backward, splat-order permutation invariance,
+fused alpha vs the white-on-black pass, and an oracle comparison on a window of tiles."""
+import pytest
+import torch
+
+from tests.helpers import make_scene, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return make_scene(1_000_000, 800, 800)
+
+
+def test_bitwise_determinism_and_linearity(hip_device, scene):
+    sp, cam, st, grads = scene
+    o1, g1 = run_hip(sp, st, grads, hip_device)
+    o2, g2 = run_hip(sp, st, grads, hip_device)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k  # no float atomics anywhere: bit-reproducible
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    # backward is linear in the upstream gradient; scaling by 2 is exact in binary floating point
+    _, g3 = run_hip(sp, st, tuple(2.0 * g for g in grads), hip_device)
+    for k in g1:
+        assert torch.equal(2.0 * g1[k], g3[k]), k
+    assert (o1["alpha"] >= 0).all() and (o1["alpha"] <= 1).all() and torch.isfinite(o1["color"]).all()
+    assert all(torch.isfinite(v).all() for v in g1.values())
+
+
+def test_permuting_the_splats_permutes_the_results(hip_device, scene):
+    sp, cam, st, grads = scene
+    o1, g1 = run_hip(sp, st, grads, hip_device)
+    perm = torch.randperm(1_000_000, generator=torch.Generator().manual_seed(5))
+    spp = {k: v[perm] for k, v in sp.items()}
+    o2, g2 = run_hip(spp, st, grads, hip_device)
+    assert torch.equal(o1["radii"][perm], o2["radii"])
+    # depth ties between distinct splats are broken by index, so a handful of pixels may reorder
+    same = (o1["color"] == o2["color"]).float().mean().item()
+    assert same > 0.999  # ~1.6k entries per tile drawn from ~8M distinct fp32 depths: a few hundred ties
+    assert torch.allclose(o1["color"], o2["color"], atol=2e-2)
+    a, b = g1["opacities"][perm], g2["opacities"]
+    assert (a == b).float().mean().item() > 0.99
+    assert torch.allclose(a, b, atol=1e-2 * a.abs().max().item())
+
+
+def test_window_against_c_oracle(hip_device, scene):
+    """All 1 M splats binned by the C oracle, a 5x5-tile window blended: compares the HIP image there."""
+    from oracle import c_oracle
+    sp, cam, st, grads = scene
+    o1, _ = run_hip(sp, st, grads, hip_device)
+    win = (22, 22, 27, 27)
+    ref, _, _ = c_oracle.rasterize(sp, st, use_sh=True, tile_window=win, threads=8)
+    sl = (slice(None), slice(win[1] * 16, win[3] * 16), slice(win[0] * 16, win[2] * 16))
+    for k in ("color", "depth", "alpha"):
+        a, b = o1[k][sl].double(), ref[k][sl].double()
+        rel = ((a - b).abs() / b.abs().clamp_min(1e-3))
+        assert rel.median().item() < 1e-5
+        assert (rel > 1e-4).float().mean().item() < 5e-3, k  # both fp32: a few pixels flip a threshold decision
+        assert rel.max().item() < 0.05
+    assert torch.equal(o1["radii"], ref["radii"])

@@ -1,0 +1,192 @@
+"""Parity of the HIP path (through the drop-in facade -> C ABI) against the CPU oracles.
+
+Tolerances (fp32 kernels vs the fp64 torch oracle; SURVEY.md Appendix A "Tolerance basis"):
+  * images (colour, depth, alpha): max relative error <= 1e-4, relative to max(|ref|, 1e-3), on every pixel
+    whose threshold decisions (alpha >= 1/255, T >= 1e-4, power <= 0) are not within the fp32 margin of
+    their threshold; the few "fragile" pixels may flip one decision: <= 2e-2 absolute;
+  * radii: exact, except where 3*sqrt(lambda_max) is within 2e-3 of an integer;
+  * gradients: max |err| <= 5e-3 * max|ref| per tensor against the fp64 oracle (threshold flips of single
+    pixel-splat pairs move a gradient by a discrete amount), and <= 1e-3 against the fp32 C oracle, which
+    makes the same decisions with the same explicit backward formulas.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import torch_oracle as O
+from tests.helpers import grad_error, image_errors, make_scene, radii_mismatch, run_hip
+from tests.test_oracle_cross import load_golden
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL, FRAGILE_TOL, GRAD_TOL64, GRAD_TOL32 = 1e-4, 2e-2, 5e-3, 1e-3
+
+
+def check_against_oracles(sp, st, grads, dev, use_sh=True, c_check=True, max_fragile=0.02):
+    out, g = run_hip(sp, st, grads, dev, use_sh=use_sh)
+    ref, gr = O.fwd_bwd(sp, st, *grads, use_sh=use_sh, dtype=torch.float64)
+    for k, r in (("color", ref.color), ("depth", ref.depth), ("alpha", ref.alpha)):
+        robust, frag = image_errors(out[k], r.detach(), ref.fragile)
+        assert robust <= IMG_TOL, (k, robust)
+        assert frag <= FRAGILE_TOL, (k, frag)
+    assert float(ref.fragile.float().mean()) < max_fragile
+    assert radii_mismatch(out["radii"], ref.pre) == 0
+    for k in g:
+        assert grad_error(g[k], gr[k]) <= GRAD_TOL64, (k, grad_error(g[k], gr[k]))
+    if c_check:
+        cout, cg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2])
+        for k in cg:
+            assert grad_error(g[k], cg[k]) <= GRAD_TOL32, ("C", k, grad_error(g[k], cg[k]))
+    return out, g, ref
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_degrees(hip_device, deg):
+    sp, cam, st, grads = make_scene(4000, 160, 120, sh_degree=deg, view=deg)
+    check_against_oracles(sp, st, grads, hip_device)
+
+
+def test_config0_10k_256(hip_device):
+    """BASELINE.json configs[0]: 10k random Gaussians, 256x256."""
+    sp, cam, st, grads = make_scene(10000, 256, 256)
+    check_against_oracles(sp, st, grads, hip_device)
+
+
+def test_precomputed_colours_ragged_image_black_bg(hip_device):
+    sp, cam, st, grads = make_scene(6000, 250, 187, bg=(0.0, 0.0, 0.0), view=5)
+    check_against_oracles(sp, st, grads, hip_device, use_sh=False)
+
+
+def test_scale_modifier_and_coloured_bg(hip_device):
+    sp, cam, st, grads = make_scene(3000, 97, 131, bg=(0.2, 0.5, 0.9), scale_modifier=0.6, view=2)
+    check_against_oracles(sp, st, grads, hip_device)
+
+
+def test_large_splats_long_tile_lists(hip_device):
+    """Big splats: lists beyond 1024 and 4096 entries per tile exercise the medium / large LDS sort classes,
+    splats clipped by the +-1.3 tanfov clamp and by the image border, and deep early termination."""
+    sp, cam, st, grads = make_scene(9000, 96, 64, mean_scale=0.25, view=3)
+    # thousands of splats per pixel: many pixels sit near the T = 1e-4 stop, all still within tolerance
+    out, g, ref = check_against_oracles(sp, st, grads, hip_device, max_fragile=0.5)
+    assert ref.num_rendered / (6 * 4) > 4096
+
+
+def test_negative_scales_are_accepted(hip_device):
+    """The neural path adds a raw MLP output to the scales (reference train.py:74): any sign; only s^2 matters."""
+    sp, cam, st, grads = make_scene(2000, 128, 96, mean_scale=0.03)
+    sp["scales"] = sp["scales"] * torch.where(torch.rand(2000, 3, generator=torch.Generator().manual_seed(3)) < 0.5, -1.0, 1.0)
+    check_against_oracles(sp, st, grads, hip_device)
+
+
+@pytest.mark.parametrize("name", ["tiny_sh3", "tiny_rgb", "tiny_sh1_mod"])
+def test_committed_golden_vectors(hip_device, name):
+    z, sp, st, grads, use_sh = load_golden(name)
+    out, g = run_hip(sp, st, grads, hip_device, use_sh=use_sh)
+    fragile = torch.tensor(z["fragile"])
+    assert torch.equal(out["radii"], torch.tensor(z["out_radii"]))
+    for k in ("color", "depth", "alpha"):
+        robust, frag = image_errors(out[k], torch.tensor(z["out_" + k]), fragile)
+        assert robust <= IMG_TOL and frag <= FRAGILE_TOL, (k, robust, frag)
+    for k in g:
+        assert grad_error(g[k], torch.tensor(z["grad_" + k])) <= GRAD_TOL64, k
+
+
+def test_empty_and_fully_culled_inputs(hip_device):
+    sp, cam, st, grads = make_scene(50, 64, 48, bg=(0.25, 0.5, 0.75))
+    empty = {k: v[:0] for k, v in sp.items()}
+    out, g = run_hip(empty, st, grads, hip_device)
+    assert torch.allclose(out["color"], torch.tensor([0.25, 0.5, 0.75])[:, None, None].expand(3, 48, 64))
+    assert (out["depth"] == 0).all() and (out["alpha"] == 0).all() and out["radii"].numel() == 0
+    # everything behind the camera: background only, radii 0, exactly-zero gradients
+    behind = {k: v.clone() for k, v in sp.items()}
+    behind["means3D"] = cam.camera_center[None] * (1.5 + torch.rand(50, 1))
+    out, g = run_hip(behind, st, grads, hip_device)
+    assert (out["radii"] == 0).all() and (out["alpha"] == 0).all()
+    assert torch.allclose(out["color"], torch.tensor([0.25, 0.5, 0.75])[:, None, None].expand(3, 48, 64))
+    for k, v in g.items():
+        assert (v == 0).all(), k
+
+
+def test_single_splat_known_answer(hip_device):
+    import math
+    sp, cam, st, grads = make_scene(1, 64, 64, bg=(0.1, 0.2, 0.3), sh_degree=0)
+    sp["means3D"] = torch.zeros(1, 3); sp["scales"] = torch.full((1, 3), 0.05); sp["rotations"] = torch.tensor([[1.0, 0, 0, 0]])
+    sp["opacities"] = torch.tensor([[0.8]]); sp["colors_precomp"] = torch.tensor([[1.0, 0.5, 0.25]])
+    out, g = run_hip(sp, st, grads, hip_device, use_sh=False)
+    z = torch.linalg.norm(cam.camera_center).item()
+    var = (64 / (2 * st.tanfovx) * 0.05 / z) ** 2 + 0.3
+    a = 0.8 * math.exp(-0.25 / var)
+    assert abs(out["alpha"][0, 31, 31].item() - a) < 1e-5
+    assert abs(out["color"][1, 31, 31].item() - (0.5 * a + (1 - a) * 0.2)) < 1e-5
+    assert abs(out["depth"][0, 31, 31].item() - z * a) < 1e-4
+    assert int(out["radii"][0]) == math.ceil(3 * math.sqrt(var))
+
+
+def test_cov3d_precomp_path(hip_device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sp, cam, st, grads = make_scene(1500, 96, 80, mean_scale=0.04)
+    cov = O.covariance3d(sp["scales"].double(), 1.0, sp["rotations"].double())
+    cov6 = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1).float()
+    dev = hip_device
+    rs = GaussianRasterizationSettings(st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.bg.to(dev), 1.0,
+                                       st.viewmatrix.to(dev), st.projmatrix.to(dev), 3, st.campos.to(dev), False, False)
+    c6 = cov6.to(dev).requires_grad_(True)
+    m3 = sp["means3D"].to(dev).requires_grad_(True)
+    color, radii, depth = GaussianRasterizer(rs)(means3D=m3, means2D=torch.zeros_like(m3), opacities=sp["opacities"].to(dev),
+                                                 shs=sp["shs"].to(dev), cov3D_precomp=c6)
+    (color * grads[0].to(dev)).sum().backward()
+    # oracle with the same precomputed covariance
+    c6_ref = cov6.double().requires_grad_(True)
+    m3_ref = sp["means3D"].double().requires_grad_(True)
+    ref = O.rasterize(m3_ref, None, sp["opacities"].double(), shs=sp["shs"].double(), cov3D_precomp=c6_ref, settings=st)
+    gm, gc = torch.autograd.grad((ref.color * grads[0].double()).sum(), [m3_ref, c6_ref])
+    robust, frag = image_errors(color.detach().cpu(), ref.color.detach(), ref.fragile)
+    assert robust <= IMG_TOL and frag <= FRAGILE_TOL
+    assert grad_error(c6.grad.cpu(), gc) <= GRAD_TOL64 and grad_error(m3.grad.cpu(), gm) <= GRAD_TOL64
+
+
+def test_render_boundary_contract(hip_device):
+    """The counterpart of gaussian_renderer/__init__.py:30-124: dict keys, shapes, dtypes, retained
+    screen-space gradient, fused alpha == the reference's second (white-on-black) pass."""
+    import types
+    from splatfields_amd.render import render
+    dev = hip_device
+    sp, cam, st, grads = make_scene(3000, 120, 88, mean_scale=0.04)
+    cam = cam.to(dev)
+    m3 = sp["means3D"].to(dev).requires_grad_(True)
+    gd = {"means3D": m3, "active_sh_degree": 2, "gaussian_opacity": sp["opacities"].to(dev),
+          "gaussian_features": sp["shs"].to(dev), "gaussian_scales": sp["scales"].to(dev),
+          "gaussian_rotations": sp["rotations"].to(dev)}
+    pipe = types.SimpleNamespace(debug=True)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=dev)
+    pkg = render(cam, gd, pipe, bg)
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "opacity", "depth"}
+    assert pkg["render"].shape == (3, 88, 120) and pkg["opacity"].shape == (1, 88, 120) and pkg["depth"].shape == (1, 88, 120)
+    assert pkg["radii"].dtype == torch.int32 and pkg["visibility_filter"].dtype == torch.bool
+    assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
+    (pkg["render"].mean() + pkg["opacity"].mean()).backward()
+    vsp = pkg["viewspace_points"]
+    assert not vsp.is_leaf and vsp.grad is not None and vsp.grad.shape == (3000, 3)
+    assert (vsp.grad[:, 2] == 0).all() and vsp.grad[pkg["visibility_filter"], :2].abs().sum() > 0
+    assert (vsp.grad[~pkg["visibility_filter"]] == 0).all()
+    # the literal two-pass call pattern of the reference gives the same alpha image
+    pkg2 = render(cam, gd, pipe, bg, two_pass=True)
+    assert torch.allclose(pkg2["opacity"], pkg["opacity"], atol=2e-6)
+    assert torch.equal(pkg2["render"], pkg["render"])
+    assert render(cam, gd, pipe, bg, return_opacity=False)["opacity"] is None
+    # precomputed-colour path of the neural model (train.py:80-81) and the rgb_fnc variant (:40-46)
+    gd2 = dict(gd); gd2.pop("gaussian_features"); gd2["gaussian_rgb"] = sp["colors_precomp"].to(dev)
+    assert render(cam, gd2, pipe, bg)["render"].shape == (3, 88, 120)
+
+
+def test_mark_visible(hip_device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sp, cam, st, grads = make_scene(5000, 64, 64)
+    dev = hip_device
+    rs = GaussianRasterizationSettings(64, 64, st.tanfovx, st.tanfovy, st.bg.to(dev), 1.0, st.viewmatrix.to(dev),
+                                       st.projmatrix.to(dev), 0, st.campos.to(dev), False, False)
+    pts = torch.cat([sp["means3D"], cam.camera_center[None] * torch.linspace(0.9, 1.2, 20)[:, None]]).to(dev)
+    vis = GaussianRasterizer(rs).markVisible(pts).cpu()
+    z = (torch.cat([pts.cpu(), torch.ones(len(pts), 1)], 1) @ st.viewmatrix)[:, 2]
+    assert torch.equal(vis, z > 0.2)
