@@ -6,7 +6,10 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libsplatraster.so"
+import os
+
+# SPLATRASTER_LIB selects an alternative build of the same ABI (A/B experiments); default: the in-tree library.
+LIB_PATH = Path(os.environ.get("SPLATRASTER_LIB") or (Path(__file__).resolve().parent / "libsplatraster.so"))
 
 c_float_p = C.c_void_p  # raw device pointers travel as integers
 

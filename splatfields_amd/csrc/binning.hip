@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     if (idx < N) {
         touched = g.touched[idx];
         rect = g.rect[idx];
-        if (touched) dbits = __float_as_uint(g.rec2[idx].w);  // view depth > 0.2: float bits sort as integers
+        if (touched) dbits = __float_as_uint(g.rec[4 * (size_t)idx].w);  // view depth > 0.2: float bits sort as integers
     }
     uint32_t total;
     const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
@@ -75,9 +75,18 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     __syncthreads();
     const uint32_t first_splat = blockIdx.x * kBlock;
     for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t i) {
+#ifdef SR_EXP_NO_SCATTER_ATOMIC
+        const uint32_t slot = base + i;
+#else
         const uint32_t slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
+#endif
+#ifdef SR_EXP_NO_SCATTER_WRITE
+        if (slot == 0xffffffffu)
+#endif
+        {
         b.keys[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(base + i);
         b.vals[slot] = first_splat + (uint32_t)e;
+        }
     });
 }
 

@@ -34,9 +34,10 @@ constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampT
 
 // ---- carved views of the caller-owned opaque buffers ---------------------------------------
 struct Geom {
-    float4* rec0;        // [N] (pix.x, pix.y, cull half-extent x, cull half-extent y)
-    float4* rec1;        // [N] (conic A, B, C, opacity)
-    float4* rec2;        // [N] (r, g, b, view depth)
+    // [N][4] one 64-byte, 64-byte-aligned record per splat, so a gather touches exactly one cache line:
+    //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) [support: d^T Q d <= tau; < 0: never visible], view depth)
+    //   q1 = (conic A, B, C, opacity)      q2 = (r, g, b, unused)      q3 = unused
+    float4* rec;
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
     uint32_t* touched;   // [N] instances emitted by this splat
     uint32_t* offsets;   // [N] exclusive prefix of `touched`
@@ -84,7 +85,7 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     const size_t nb = (n + kBlock - 1) / kBlock;
     const size_t tiles = (size_t)tiles_x(W) * tiles_y(H);
     Geom t;
-    t.rec0 = c.take<float4>(n); t.rec1 = c.take<float4>(n); t.rec2 = c.take<float4>(n);
+    t.rec = c.take<float4>(4 * n);
     t.rect = c.take<ushort4>(n);
     t.touched = c.take<uint32_t>(n); t.offsets = c.take<uint32_t>(n);
     t.flags = c.take<uint8_t>(n);
@@ -142,6 +143,9 @@ __device__ __forceinline__ float dpp_add(float v) {
 
 // Sum over the 64 lanes of a wavefront; the total is valid in lane 63 only.
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#ifdef SR_EXP_NO_REDUCE
+    return v;
+#endif
     v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
     v = dpp_add<0x124>(v);       // row_ror:4
@@ -190,10 +194,26 @@ __device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_
     return (power <= 0.0f) && (alpha >= kAlphaMin);
 }
 
-// Conservative test: can the splat reach any pixel centre of the 8x8 block whose first pixel is (sx, sy)?
-__device__ __forceinline__ bool subtile_overlap(const float4 r0, float sx, float sy) {
-    return (r0.z >= 0.0f) && (r0.x + r0.z >= sx) && (r0.x - r0.z <= sx + (kSub - 1)) &&
-           (r0.y + r0.w >= sy) && (r0.y - r0.w <= sy + (kSub - 1));
+// Exact (up to a safety margin) test: is there a point of the 8x8 pixel-centre box starting at (sx, sy) where
+// the splat's alpha can reach 1/255, i.e. min over the box of d^T Q d <= tau?  The minimum of a convex
+// quadratic over a box is at the centre if it is inside, else on one of the 4 edges (1-D clamped minima).
+__device__ __forceinline__ float edge_min(float a, float b2, float c, float fixed, float lo, float hi) {
+    // min over t in [lo,hi] of a*fixed^2 + b2*fixed*t + c*t^2   (b2 = 2B)
+    const float t = fminf(hi, fmaxf(lo, -0.5f * b2 * fixed / c));
+    return a * fixed * fixed + (b2 * fixed + c * t) * t;
+}
+__device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1, float sx, float sy) {
+    const float tau = r0.z;
+    if (!(tau > 0.0f)) return false;
+    const float x0 = sx - r0.x, x1 = x0 + (kSub - 1), y0 = sy - r0.y, y1 = y0 + (kSub - 1);  // box relative to the centre
+    const bool in_x = x0 <= 0.0f && x1 >= 0.0f, in_y = y0 <= 0.0f && y1 >= 0.0f;
+    if (in_x && in_y) return true;
+    const float A = r1.x, B2 = 2.0f * r1.y, C = r1.z;
+    float fmin_ = edge_min(A, B2, C, x0, y0, y1);
+    fmin_ = fminf(fmin_, edge_min(A, B2, C, x1, y0, y1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, y0, x0, x1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, y1, x0, x1));
+    return fmin_ <= tau * 1.002f + 0.02f;
 }
 
 #endif  // __HIPCC__

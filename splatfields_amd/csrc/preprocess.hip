@@ -89,16 +89,34 @@ __device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
 // ------------------------------------------------------------------------------------------
 // Forward preprocess
 // ------------------------------------------------------------------------------------------
+// SH staging: with K = 16 coefficients a splat's SH block is 192 contiguous bytes, so the 256 splats of a
+// workgroup own one contiguous 48 KiB span.  It is moved with fully coalesced 16-byte loads/stores through LDS
+// (rows padded to 13 float4 = 208 B) instead of 48 strided 4-byte accesses per lane.
+constexpr int kShRowF4 = 13;
+
+template <bool STAGE_SH>
 __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
     __shared__ uint32_t s_off[kBlock + 1];
     __shared__ ushort4 s_rect[kBlock];
     __shared__ uint32_t s_scan[8];
+    __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
     uint32_t touched = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
+
+    if constexpr (STAGE_SH) {
+        const size_t first = (size_t)blockIdx.x * kBlock;
+        const int n_here = min(kBlock, s.N - (int)first);
+        const float4* src = reinterpret_cast<const float4*>(s.shs + first * 48);
+        for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
+            const int sp = i / 12;
+            s_sh[sp * kShRowF4 + (i - sp * 12)] = src[i];
+        }
+        __syncthreads();
+    }
 
     if (idx < s.N) {
         int out_radius = 0;
@@ -178,7 +196,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         d.x *= inv_len; d.y *= inv_len; d.z *= inv_len;
                         float B[16];
                         sh_basis(v.sh_degree, d, B);
-                        const float* sh = s.shs + (size_t)idx * v.sh_coeffs * 3;
+                        const float* sh = STAGE_SH ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4])
+                                                   : s.shs + (size_t)idx * v.sh_coeffs * 3;
                         const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
                         rgb = make_float3(0.f, 0.f, 0.f);
                         for (int k = 0; k < nb; ++k) {
@@ -189,9 +208,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         if (rgb.y < 0.f) { flags |= kFlagClampG; rgb.y = 0.f; }
                         if (rgb.z < 0.f) { flags |= kFlagClampB; rgb.z = 0.f; }
                     }
-                    g.rec0[idx] = make_float4(px, py, ex, ey);
-                    g.rec1[idx] = make_float4(cA, cB, cC, opac);
-                    g.rec2[idx] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);
+                    float4* rec = g.rec + 4 * (size_t)idx;
+                    rec[0] = make_float4(px, py, tau > 0.0f ? tau : -1.0f, pv.z);
+                    rec[1] = make_float4(cA, cB, cC, opac);
+                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
                 }
             }
         }
@@ -209,14 +229,19 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     if (threadIdx.x == 0) { s_off[kBlock] = total; g.block_sums[blockIdx.x] = total; }
     __syncthreads();
     for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
+#ifndef SR_EXP_NO_COUNT
         atomicAdd(&g.tile_count[tile], 1u);
+#endif
     });
 }
 
 void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st) {
     const int nb = (s.N + kBlock - 1) / kBlock;
     hipMemsetAsync(g.tile_count, 0, sizeof(uint32_t) * (size_t)v.gx * v.gy, st);
-    if (nb > 0) hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    if (nb <= 0) return;
+    const bool stage = s.shs && v.sh_coeffs == 16 && v.sh_degree >= 2;  // below degree 2 only <= 48 of the 192 bytes are needed
+    if (stage) hipLaunchKernelGGL(k_preprocess<true>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    else hipLaunchKernelGGL(k_preprocess<false>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -238,11 +263,27 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 // ------------------------------------------------------------------------------------------
 // Backward preprocess
 // ------------------------------------------------------------------------------------------
+template <bool STAGE_SH>
 __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
                                                                 const int* __restrict__ radii,
                                                                 const float* __restrict__ slots, const GradsK gr) {
+    __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
     const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= s.N) return;
+    const bool valid = idx < s.N;
+    const bool stage_read = STAGE_SH && v.sh_degree >= 2;
+    if constexpr (STAGE_SH) {
+        if (stage_read) {
+            const size_t first = (size_t)blockIdx.x * kBlock;
+            const int n_here = min(kBlock, s.N - (int)first);
+            const float4* src = reinterpret_cast<const float4*>(s.shs + first * 48);
+            for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
+                const int sp = i / 12;
+                s_sh[sp * kShRowF4 + (i - sp * 12)] = src[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
     const int K = v.sh_coeffs;
@@ -270,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             db += c.x; dd += c.y;
         }
         flags = g.flags[idx];
-        const float4 r1 = g.rec1[idx];
+        const float4 r1 = g.rec[4 * (size_t)idx + 1];
         const float A = r1.x, B = r1.y, C = r1.z, o = r1.w;
         d_opac = S0;
         d_rgb = make_float3(dr, dg, db);
@@ -379,7 +420,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 
     // ---- colour: SH coefficients and view direction, or precomputed colours ----
     if (gr.shs) {
-        float* out = gr.shs + (size_t)idx * K * 3;
+        // staged: this thread's LDS row first supplies its SH coefficients, then receives its gradients
+        float* out = STAGE_SH ? reinterpret_cast<float*>(&s_sh[threadIdx.x * kShRowF4]) : gr.shs + (size_t)idx * K * 3;
         int nb = 0;
         if (visible) {
             nb = (v.sh_degree + 1) * (v.sh_degree + 1);
@@ -393,11 +435,13 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
             float B[16];
             sh_basis(v.sh_degree, d, B);
-            const float* sh = s.shs + (size_t)idx * K * 3;
+            const float* sh = stage_read ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4])
+                                         : s.shs + (size_t)idx * K * 3;
             float gk[16];  // gk[k] = sh[k] . dL/dRGB
             for (int k = 0; k < nb; ++k) {
+                const float c0 = sh[3 * k], c1 = sh[3 * k + 1], c2 = sh[3 * k + 2];  // read before the row is overwritten
+                gk[k] = c0 * dc.x + c1 * dc.y + c2 * dc.z;
                 out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z;
-                gk[k] = sh[3 * k] * dc.x + sh[3 * k + 1] * dc.y + sh[3 * k + 2] * dc.z;
             }
             float3 dd_ = make_float3(0.f, 0.f, 0.f);  // dL/d(unit direction)
             if (v.sh_degree > 0) {
@@ -437,12 +481,25 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     if (gr.scales) { gr.scales[3 * idx] = d_scale.x; gr.scales[3 * idx + 1] = d_scale.y; gr.scales[3 * idx + 2] = d_scale.z; }
     if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
+    }  // valid
+    if constexpr (STAGE_SH) {
+        __syncthreads();
+        const size_t first = (size_t)blockIdx.x * kBlock;
+        const int n_here = min(kBlock, s.N - (int)first);
+        float4* dst = reinterpret_cast<float4*>(gr.shs + first * 48);
+        for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
+            const int sp = i / 12;
+            dst[i] = s_sh[sp * kShRowF4 + (i - sp * 12)];
+        }
+    }
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
                                 const float* slots, const GradsK& gr, hipStream_t st) {
     const int nb = (s.N + kBlock - 1) / kBlock;
-    if (nb > 0) hipLaunchKernelGGL(k_preprocess_backward, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    if (nb <= 0) return;
+    if (gr.shs && v.sh_coeffs == 16) hipLaunchKernelGGL(k_preprocess_backward<true>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    else hipLaunchKernelGGL(k_preprocess_backward<false>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
 }
 
 }  // namespace sr

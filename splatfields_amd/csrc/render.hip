@@ -26,6 +26,20 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+
+// x, y hold two different quantities per lane.  Returns r with r[l] = x[l] + x[l+32] for l < 32 and
+// r[l] = y[l-32] + y[l] for l >= 32 (one v_permlane32_swap + one add): each half-wave now owns one quantity.
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// Same one level down: rows (16 lanes) 0 and 2 end up with x's row pairs (0+1, 2+3), rows 1 and 3 with y's.
+__device__ __forceinline__ float swap16_add(float x, float y) {
+    const uint2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
@@ -56,9 +70,10 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         const uint32_t i = base + threadIdx.x;
         if (i < end) {
             const uint32_t id = b.sorted_id[i];
-            s_r0[threadIdx.x] = g.rec0[id];
-            s_r1[threadIdx.x] = g.rec1[id];
-            s_r2[threadIdx.x] = g.rec2[id];
+            const float4* rec = g.rec + 4 * (size_t)id;
+            s_r0[threadIdx.x] = rec[0];
+            s_r1[threadIdx.x] = rec[1];
+            s_r2[threadIdx.x] = rec[2];
         }
         __syncthreads();
         const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
@@ -66,7 +81,8 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             int m = 0;
             for (int c = 0; c < cnt; c += kWave) {
                 const int e = c + lane;
-                const bool ok = e < cnt && subtile_overlap(s_r0[e < cnt ? e : 0], sxf, syf);
+                const int ec = e < cnt ? e : 0;
+                const bool ok = e < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
                 const uint64_t mask = __ballot(ok);
                 if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
                 m += __popcll(mask);
@@ -83,7 +99,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                             done = true;
                         } else {
                             const float w = alpha * T;
-                            Cr += r2.x * w; Cg += r2.y * w; Cb += r2.z * w; D += r2.w * w;
+                            Cr += r2.x * w; Cg += r2.y * w; Cb += r2.z * w; D += r0.w * w;
                             T = test_T;
                             last = (base - start) + (uint32_t)e + 1u;
                         }
@@ -174,9 +190,10 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         if ((int)threadIdx.x < cnt) {
             const uint32_t pos = start + (uint32_t)(top - 1 - (int)threadIdx.x);
             const uint32_t id = b.sorted_id[pos];
-            s_r0[threadIdx.x] = g.rec0[id];
-            s_r1[threadIdx.x] = g.rec1[id];
-            s_r2[threadIdx.x] = g.rec2[id];
+            const float4* rec = g.rec + 4 * (size_t)id;
+            s_r0[threadIdx.x] = rec[0];
+            s_r1[threadIdx.x] = rec[1];
+            s_r2[threadIdx.x] = rec[2];
             s_inst[threadIdx.x] = b.sorted_inst[pos];
         }
         {
@@ -188,47 +205,70 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
             int m = 0;
             for (int c = 0; c < cnt; c += kWave) {
                 const int e = c + lane;
-                const bool ok = e < cnt && (top - 1 - e) < wmax && subtile_overlap(s_r0[e < cnt ? e : 0], sxf, syf);
+                const int ec = e < cnt ? e : 0;
+                const bool ok = e < cnt && (top - 1 - e) < wmax && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
                 const uint64_t mask = __ballot(ok);
                 if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
                 m += __popcll(mask);
             }
             wave_lds_fence();
-            for (int k = 0; k < m; ++k) {
-                const int e = s_list[wave][k];
-                const int pos = top - 1 - e;
-                const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-                const float dx = r0.x - pxf, dy = r0.y - pyf;
-                float G = 0.f, alpha = 0.f;
-                bool contrib = false;
-                if (pos < my_last) contrib = pair_alpha(dx, dy, r1, G, alpha);
-                if (__ballot(contrib) == 0ull) continue;
-                float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dd = 0.f;
-                if (contrib) {
-                    T = T / (1.0f - alpha);
-                    const float wgt = alpha * T;
-                    const float keep = 1.0f - last_alpha;
-                    acR = last_alpha * lR + keep * acR; lR = r2.x;
-                    acG = last_alpha * lG + keep * acG; lG = r2.y;
-                    acB = last_alpha * lB + keep * acB; lB = r2.z;
-                    acD = last_alpha * lD + keep * acD; lD = r2.w;
-                    acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
-                    float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r2.w - acD) * gD + (1.0f - acA) * gA;
-                    dLa *= T;
-                    last_alpha = alpha;
-                    dLa += (-T_final / (1.0f - alpha)) * bg_dot;
-                    const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
-                    S0 = g1; Sx = g1 * dx; Sy = g1 * dy; Sxx = Sx * dx; Sxy = Sx * dy; Syy = Sy * dy;
-                    dr = wgt * gR; dg = wgt * gG; db = wgt * gB; dd = wgt * gD;
+            // 4 list entries per step: their 4 x 10 per-lane partial sums are reduced together by a butterfly
+            // (v_permlane32_swap, v_permlane16_swap, then 4 DPP steps inside each row of 16 lanes):
+            // 100 cross-lane adds per 4 entries instead of 4 x 60.
+            for (int k0 = 0; k0 < m; k0 += 4) {
+                float pv[4][10];
+                int ent[4];
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool live = (k0 + q) < m;
+                    const int e = live ? (int)s_list[wave][k0 + q] : 0;
+                    ent[q] = live ? e : -1;
+                    const int pos = top - 1 - e;
+                    const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+                    const float dx = r0.x - pxf, dy = r0.y - pyf;
+                    float G = 0.f, alpha = 0.f;
+                    bool contrib = false;
+                    if (live && pos < my_last) contrib = pair_alpha(dx, dy, r1, G, alpha);
+#pragma unroll
+                    for (int c = 0; c < 10; ++c) pv[q][c] = 0.f;
+                    if (contrib) {
+                        T = T / (1.0f - alpha);
+                        const float wgt = alpha * T;
+                        const float keep = 1.0f - last_alpha;
+                        acR = last_alpha * lR + keep * acR; lR = r2.x;
+                        acG = last_alpha * lG + keep * acG; lG = r2.y;
+                        acB = last_alpha * lB + keep * acB; lB = r2.z;
+                        acD = last_alpha * lD + keep * acD; lD = r0.w;
+                        acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
+                        float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r0.w - acD) * gD + (1.0f - acA) * gA;
+                        dLa *= T;
+                        last_alpha = alpha;
+                        dLa += (-T_final / (1.0f - alpha)) * bg_dot;
+                        const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
+                        const float sxv = g1 * dx, syv = g1 * dy;
+                        pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
+                        pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
+                    }
+                    any = any || contrib;
                 }
-                S0 = wave_sum_to_lane63(S0); Sx = wave_sum_to_lane63(Sx); Sy = wave_sum_to_lane63(Sy);
-                Sxx = wave_sum_to_lane63(Sxx); Sxy = wave_sum_to_lane63(Sxy); Syy = wave_sum_to_lane63(Syy);
-                dr = wave_sum_to_lane63(dr); dg = wave_sum_to_lane63(dg); db = wave_sum_to_lane63(db);
-                dd = wave_sum_to_lane63(dd);
-                if (lane == 63) {
-                    s_acc[wave][e][0] = make_float4(S0, Sx, Sy, Sxx);
-                    s_acc[wave][e][1] = make_float4(Sxy, Syy, dr, dg);
-                    s_acc[wave][e][2] = make_float4(db, dd, 0.f, 0.f);
+                if (__ballot(any) == 0ull) continue;
+                float red[10];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {
+                    const float z01 = swap32_add(pv[0][c], pv[1][c]);   // lanes 0-31: entry 0, lanes 32-63: entry 1
+                    const float z23 = swap32_add(pv[2][c], pv[3][c]);   // lanes 0-31: entry 2, lanes 32-63: entry 3
+                    float w = swap16_add(z01, z23);                     // rows: 0 -> entry 0, 1 -> entry 2, 2 -> entry 1, 3 -> entry 3
+                    w = dpp_add<0xB1>(w); w = dpp_add<0x4E>(w); w = dpp_add<0x124>(w); w = dpp_add<0x128>(w);
+                    red[c] = w;
+                }
+                const int row = lane >> 4;
+                const int q_of_row = ((row & 1) << 1) | (row >> 1);
+                const int e_mine = q_of_row == 0 ? ent[0] : (q_of_row == 1 ? ent[1] : (q_of_row == 2 ? ent[2] : ent[3]));
+                if ((lane & 15) == 0 && e_mine >= 0) {
+                    s_acc[wave][e_mine][0] = make_float4(red[0], red[1], red[2], red[3]);
+                    s_acc[wave][e_mine][1] = make_float4(red[4], red[5], red[6], red[7]);
+                    s_acc[wave][e_mine][2] = make_float4(red[8], red[9], 0.f, 0.f);
                 }
             }
         }
