@@ -101,10 +101,9 @@ int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, i
     const sr::SplatsK s = make_splats(splats);
     sr::Geom g;
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
-    const int nb = (s.N + sr::kBlock - 1) / sr::kBlock;
     { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
     SR_TRY(after_launch(view, st, "preprocess"));
-    { StageTimer t_(1, st); sr::launch_scan_small(g, nb, v.gx * v.gy, st); }
+    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, st); }
     SR_TRY(after_launch(view, st, "scan"));
     uint32_t total = 0;
     SR_TRY(check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));

@@ -15,20 +15,101 @@
 
 namespace sr {
 
+// ---- atomic-free per-tile counts: count matrix [chunk][tile] built with LDS atomics only ----------
+// A chunk is a run of consecutive 256-splat sub-batches owned by one workgroup.  The workgroup keeps a
+// histogram over ALL tiles in LDS (800x800 -> 2500 counters = 10 KiB of the CU's 160 KiB), walks its
+// sub-batches with the block-cooperative expansion, and writes its row of the matrix once, coalesced.
+// (Measured on MI355X: 2.3 M device-scope atomics on 2500 counters cost ~0.17 ms without return value and
+// ~0.24 ms with; LDS atomics + a 10 MB matrix cost a few microseconds.)
+__global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, const Geom g, const Chunking ch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [tiles_padded]
+    __shared__ uint32_t s_off[kBlock + 1];
+    __shared__ ushort4 s_rect[kBlock];
+    __shared__ uint32_t s_scan[8];
+    for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
+    const int sb0 = blockIdx.x * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+    for (int sb = sb0; sb < sb1; ++sb) {
+        const int idx = sb * kBlock + threadIdx.x;
+        uint32_t touched = 0;
+        ushort4 rect = make_ushort4(0, 0, 0, 0);
+        if (idx < N) { touched = g.touched[idx]; rect = g.rect[idx]; }
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // starts with a barrier: protects s_off reuse
+        s_off[threadIdx.x] = excl;
+        s_rect[threadIdx.x] = rect;
+        if (threadIdx.x == 0) s_off[kBlock] = total;
+        __syncthreads();
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
+            atomicAdd(&s_hist[tile], 1u);  // LDS atomic
+        });
+    }
+    __syncthreads();
+    uint32_t* row = g.cnt + (size_t)blockIdx.x * ch.tiles_padded;
+    for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) row[t] = s_hist[t];
+}
+
+// Exclusive prefix along the chunk axis, per tile column, inside one segment of kSegRows chunks.
+// grid = (tiles_padded / 64, segments); the 128 x 64 sub-matrix is transposed through LDS so both the
+// loads and the stores are row-contiguous.
+__global__ void __launch_bounds__(kBlock) k_colscan_local(const Geom g, const Chunking ch) {
+    __shared__ uint32_t s_m[kSegRows][65];
+    __shared__ uint32_t s_part[4][64];
+    const int col0 = blockIdx.x * 64, row0 = blockIdx.y * kSegRows;
+    for (int i = threadIdx.x; i < kSegRows * 64; i += kBlock) {
+        const int r = i >> 6, c = i & 63;
+        s_m[r][c] = (row0 + r < ch.chunks) ? g.cnt[(size_t)(row0 + r) * ch.tiles_padded + col0 + c] : 0u;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    uint32_t run = 0;
+    for (int r = part * 32; r < part * 32 + 32; ++r) { const uint32_t x = s_m[r][c]; s_m[r][c] = run; run += x; }
+    s_part[part][c] = run;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int p2 = 0; p2 < part; ++p2) base += s_part[p2][c];
+    for (int r = part * 32; r < part * 32 + 32; ++r) s_m[r][c] += base;
+    if (part == 3) g.segtot[(size_t)blockIdx.y * ch.tiles_padded + col0 + c] = base + run;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSegRows * 64; i += kBlock) {
+        const int r = i >> 6, cc = i & 63;
+        if (row0 + r < ch.chunks) g.cnt[(size_t)(row0 + r) * ch.tiles_padded + col0 + cc] = s_m[r][cc];
+    }
+}
+
+void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
+    if (!use_count_matrix(v) || N <= 0) return;
+    const Chunking ch = make_chunking(N, v.gx * v.gy);
+    hipLaunchKernelGGL(k_count_tiles, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, ch);
+    hipLaunchKernelGGL(k_colscan_local, dim3(ch.tiles_padded / 64, ch.segments), dim3(kBlock), 0, st, g, ch);
+}
+
 // ---- two small prefix sums in one launch ---------------------------------------------------
-// block 0: block_sums[n_blocks] -> block_offsets, grand total -> total[0]
-// block 1: tile_count[n_tiles]  -> tile_start[n_tiles + 1]; clears tile_cursor
-__global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_blocks, int n_tiles) {
+// block 0: block_sums[n_sub] -> block_offsets, grand total -> total[0]
+// block 1: per-tile totals (count-matrix path: sum of the segment totals, also producing the exclusive
+//          prefix over segments; fallback path: the atomically accumulated tile_count) -> tile_start[tiles+1];
+//          clears tile_cursor
+__global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, int n_tiles, const Chunking ch, int use_matrix) {
     __shared__ uint32_t s_wave[16];
     const bool tiles = blockIdx.x == 1;
-    const uint32_t* src = tiles ? g.tile_count : g.block_sums;
     uint32_t* dst = tiles ? g.tile_start : g.block_offsets;
-    const int n = tiles ? n_tiles : n_blocks;
+    const int n = tiles ? n_tiles : n_sub;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint32_t carry = 0;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
-        const uint32_t v = i < n ? src[i] : 0u;
+        uint32_t v = 0;
+        if (i < n) {
+            if (!tiles) v = g.block_sums[i];
+            else if (!use_matrix) v = g.tile_count[i];
+            else {
+                for (int sg = 0; sg < ch.segments; ++sg) {
+                    const size_t at = (size_t)sg * ch.tiles_padded + i;
+                    const uint32_t x = g.segtot[at];
+                    g.segbase[at] = v;
+                    v += x;
+                }
+            }
+        }
         const uint32_t inc = wave_inclusive_scan(v);
         if (lane == 63) s_wave[w] = inc;
         __syncthreads();
@@ -45,54 +126,69 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_blocks,
     if (tid == 0) { if (tiles) dst[n] = carry; else g.total[0] = carry; }
 }
 
-void launch_scan_small(const Geom& g, int n_blocks, int n_tiles, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, st, g, n_blocks, n_tiles);
+void launch_scan_small(const ViewK& v, int N, const Geom& g, hipStream_t st) {
+    const Chunking ch = make_chunking(N, v.gx * v.gy);
+    hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, st, g, (N + kBlock - 1) / kBlock, v.gx * v.gy, ch,
+                       use_count_matrix(v) ? 1 : 0);
 }
 
 // ---- emit instances straight into their tile's segment -------------------------------------
-__global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geom g, const Binning b) {
+// MATRIX: the workgroup owns the same chunk as in k_count_tiles; its write cursors
+//   tile_start[t] + (prefix over earlier segments) + (prefix over earlier chunks of this segment)
+// live in LDS, so slot allocation is an LDS atomic.  The order inside a (chunk, tile) group is
+// arbitrary; the per-tile sort below imposes a total order, so the final lists are deterministic.
+template <bool MATRIX>
+__global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geom g, const Binning b, const Chunking ch) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_cur[];  // [tiles_padded] (MATRIX only)
     __shared__ uint32_t s_off[kBlock + 1];
     __shared__ ushort4 s_rect[kBlock];
     __shared__ uint32_t s_depth[kBlock];
     __shared__ uint32_t s_scan[8];
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t touched = 0;
-    ushort4 rect = make_ushort4(0, 0, 0, 0);
-    uint32_t dbits = 0;
-    if (idx < N) {
-        touched = g.touched[idx];
-        rect = g.rect[idx];
-        if (touched) dbits = __float_as_uint(g.rec[4 * (size_t)idx].w);  // view depth > 0.2: float bits sort as integers
+    int sb0 = blockIdx.x, sb1 = blockIdx.x + 1;
+    if constexpr (MATRIX) {
+        sb0 = blockIdx.x * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+        const uint32_t* row = g.cnt + (size_t)blockIdx.x * ch.tiles_padded;
+        const uint32_t* sbase = g.segbase + (size_t)(blockIdx.x / kSegRows) * ch.tiles_padded;
+        const int n_tiles = v.gx * v.gy;
+        for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + sbase[t] + row[t];
     }
-    uint32_t total;
-    const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
-    const uint32_t base = g.block_offsets[blockIdx.x];
-    if (idx < N) g.offsets[idx] = base + excl;
-    s_off[threadIdx.x] = excl;
-    s_rect[threadIdx.x] = rect;
-    s_depth[threadIdx.x] = dbits;
-    if (threadIdx.x == 0) s_off[kBlock] = total;
-    __syncthreads();
-    const uint32_t first_splat = blockIdx.x * kBlock;
-    for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t i) {
-#ifdef SR_EXP_NO_SCATTER_ATOMIC
-        const uint32_t slot = base + i;
-#else
-        const uint32_t slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
-#endif
-#ifdef SR_EXP_NO_SCATTER_WRITE
-        if (slot == 0xffffffffu)
-#endif
-        {
-        b.keys[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(base + i);
-        b.vals[slot] = first_splat + (uint32_t)e;
+    for (int sb = sb0; sb < sb1; ++sb) {
+        const int idx = sb * kBlock + threadIdx.x;
+        uint32_t touched = 0;
+        ushort4 rect = make_ushort4(0, 0, 0, 0);
+        uint32_t dbits = 0;
+        if (idx < N) {
+            touched = g.touched[idx];
+            rect = g.rect[idx];
+            if (touched) dbits = __float_as_uint(g.rec[4 * (size_t)idx].w);  // view depth > 0.2: float bits sort as integers
         }
-    });
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // leading barrier protects LDS reuse
+        const uint32_t base = g.block_offsets[sb];
+        if (idx < N) g.offsets[idx] = base + excl;
+        s_off[threadIdx.x] = excl;
+        s_rect[threadIdx.x] = rect;
+        s_depth[threadIdx.x] = dbits;
+        if (threadIdx.x == 0) s_off[kBlock] = total;
+        __syncthreads();
+        const uint32_t first_splat = (uint32_t)sb * kBlock;
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t i) {
+            uint32_t slot;
+            if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
+            else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
+            b.keys[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(base + i);
+            b.vals[slot] = first_splat + (uint32_t)e;
+        });
+    }
 }
 
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st) {
-    const int nb = (N + kBlock - 1) / kBlock;
-    if (nb > 0) hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kBlock), 0, st, v, N, g, b);
+    if (N <= 0) return;
+    const Chunking ch = make_chunking(N, v.gx * v.gy);
+    if (use_count_matrix(v))
+        hipLaunchKernelGGL(k_emit<true>, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, b, ch);
+    else
+        hipLaunchKernelGGL(k_emit<false>, dim3(ch.n_sub), dim3(kBlock), 0, st, v, N, g, b, ch);
 }
 
 // ---- per-tile sort in LDS --------------------------------------------------------------------

@@ -48,7 +48,27 @@ struct Geom {
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
     uint32_t* total;         // [1] number of instances
+    // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
+    uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
+    uint32_t* segtot;        // [segments][tiles_padded] column totals per segment of kSegRows chunks
+    uint32_t* segbase;       // [segments][tiles_padded] exclusive prefix of segtot over segments
 };
+
+constexpr int kMaxChunks = 1024;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
+constexpr int kSegRows = 128;           // chunks per column-scan segment
+constexpr int kMaxMatrixTiles = 16384;  // LDS histogram of 64 KiB; larger images use the global-atomic fallback
+
+struct Chunking { int n_sub, chunks, sub_per_chunk, segments, tiles_padded; };
+inline Chunking make_chunking(int N, int tiles) {
+    Chunking c;
+    c.n_sub = (N + 255) / 256; if (c.n_sub < 1) c.n_sub = 1;
+    const int b = c.n_sub < kMaxChunks ? c.n_sub : kMaxChunks;
+    c.sub_per_chunk = (c.n_sub + b - 1) / b;
+    c.chunks = (c.n_sub + c.sub_per_chunk - 1) / c.sub_per_chunk;
+    c.segments = (c.chunks + kSegRows - 1) / kSegRows;
+    c.tiles_padded = (tiles + 63) / 64 * 64;
+    return c;
+}
 
 struct Binning {
     uint64_t* keys;      // [R] (depth bits << 32) | instance index, bucketed per tile, unsorted
@@ -92,6 +112,13 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
     t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);
     t.tile_cursor = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
+    t.cnt = t.segtot = t.segbase = nullptr;
+    if (tiles <= (size_t)kMaxMatrixTiles) {
+        const Chunking ch = make_chunking(N, (int)tiles);
+        t.cnt = c.take<uint32_t>((size_t)ch.chunks * ch.tiles_padded);
+        t.segtot = c.take<uint32_t>((size_t)ch.segments * ch.tiles_padded);
+        t.segbase = c.take<uint32_t>((size_t)ch.segments * ch.tiles_padded);
+    }
     if (g) *g = t;
     return align_up(c.off, 256);
 }

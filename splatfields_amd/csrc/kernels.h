@@ -21,7 +21,10 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
                                 const float* slots, const GradsK& gr, hipStream_t st);
 // binning.hip
-void launch_scan_small(const Geom& g, int n_blocks, int n_tiles, hipStream_t st);
+// true when the image is small enough for the atomic-free count-matrix bucketing
+inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixTiles; }
+void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st);
+void launch_scan_small(const ViewK& v, int N, const Geom& g, hipStream_t st);
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st);
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, hipStream_t st);
 // render.hip

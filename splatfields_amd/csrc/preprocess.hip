@@ -94,10 +94,10 @@ __device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
 // (rows padded to 13 float4 = 208 B) instead of 48 strided 4-byte accesses per lane.
 constexpr int kShRowF4 = 13;
 
-template <bool STAGE_SH>
+template <bool STAGE_SH, bool COUNT_ATOMIC>
 __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
-    __shared__ uint32_t s_off[kBlock + 1];
-    __shared__ ushort4 s_rect[kBlock];
+    __shared__ uint32_t s_off[COUNT_ATOMIC ? kBlock + 1 : 1];
+    __shared__ ushort4 s_rect[COUNT_ATOMIC ? kBlock : 1];
     __shared__ uint32_t s_scan[8];
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
 
@@ -221,27 +221,33 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         g.flags[idx] = flags;
     }
 
-    // per-tile instance counts (block-cooperative expansion keeps large splats from serialising a lane)
+    // instances emitted by this 256-splat sub-batch (input of the global exclusive scan)
     uint32_t total;
     const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
-    s_off[threadIdx.x] = excl;
-    s_rect[threadIdx.x] = rect;
-    if (threadIdx.x == 0) { s_off[kBlock] = total; g.block_sums[blockIdx.x] = total; }
-    __syncthreads();
-    for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
-#ifndef SR_EXP_NO_COUNT
-        atomicAdd(&g.tile_count[tile], 1u);
-#endif
-    });
+    if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    if constexpr (COUNT_ATOMIC) {
+        // fallback for very large images: per-tile counts with global atomics
+        // (block-cooperative expansion keeps large splats from serialising a lane)
+        s_off[threadIdx.x] = excl;
+        s_rect[threadIdx.x] = rect;
+        if (threadIdx.x == 0) s_off[kBlock] = total;
+        __syncthreads();
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
+            atomicAdd(&g.tile_count[tile], 1u);
+        });
+    }
 }
 
 void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st) {
     const int nb = (s.N + kBlock - 1) / kBlock;
-    hipMemsetAsync(g.tile_count, 0, sizeof(uint32_t) * (size_t)v.gx * v.gy, st);
+    const bool atomic = !use_count_matrix(v);
+    if (atomic) hipMemsetAsync(g.tile_count, 0, sizeof(uint32_t) * (size_t)v.gx * v.gy, st);
     if (nb <= 0) return;
     const bool stage = s.shs && v.sh_coeffs == 16 && v.sh_degree >= 2;  // below degree 2 only <= 48 of the 192 bytes are needed
-    if (stage) hipLaunchKernelGGL(k_preprocess<true>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
-    else hipLaunchKernelGGL(k_preprocess<false>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    if (stage && atomic) hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    else if (stage) hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    else if (atomic) hipLaunchKernelGGL((k_preprocess<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
+    else hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
 }
 
 // ------------------------------------------------------------------------------------------

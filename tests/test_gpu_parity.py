@@ -190,3 +190,17 @@ def test_mark_visible(hip_device):
     vis = GaussianRasterizer(rs).markVisible(pts).cpu()
     z = (torch.cat([pts.cpu(), torch.ones(len(pts), 1)], 1) @ st.viewmatrix)[:, 2]
     assert torch.equal(vis, z > 0.2)
+
+
+def test_large_image_global_atomic_fallback(hip_device):
+    """> 16384 tiles: the count-matrix bucketing does not fit LDS and the global-atomic path is used."""
+    sp, cam, st, grads = make_scene(4000, 2080, 2064, mean_scale=0.02)
+    assert (2080 // 16) * (2064 // 16) > 16384
+    out, g = run_hip(sp, st, grads, hip_device)
+    cout, cg, _ = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=8)
+    assert torch.equal(out["radii"], cout["radii"])
+    for k in ("color", "depth", "alpha"):
+        rel = (out[k].double() - cout[k].double()).abs() / cout[k].double().abs().clamp_min(1e-3)
+        assert (rel > 1e-4).float().mean().item() < 1e-4 and rel.max().item() < 0.05, k
+    for k in cg:
+        assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
