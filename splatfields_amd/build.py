@@ -32,6 +32,9 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and not is_stale():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           # the SLP vectoriser pairs fp32 adds into v_pk_add_f32, which blocks DPP fusion (v_add_f32_dpp) in the
+           # wave reductions and costs extra v_mov shuffles in the VALU-bound blend loops
+           "-fno-slp-vectorize",
            "-o", str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))

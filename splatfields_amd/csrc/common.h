@@ -224,9 +224,10 @@ __device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_
 // Exact (up to a safety margin) test: is there a point of the 8x8 pixel-centre box starting at (sx, sy) where
 // the splat's alpha can reach 1/255, i.e. min over the box of d^T Q d <= tau?  The minimum of a convex
 // quadratic over a box is at the centre if it is inside, else on one of the 4 edges (1-D clamped minima).
-__device__ __forceinline__ float edge_min(float a, float b2, float c, float fixed, float lo, float hi) {
-    // min over t in [lo,hi] of a*fixed^2 + b2*fixed*t + c*t^2   (b2 = 2B)
-    const float t = fminf(hi, fmaxf(lo, -0.5f * b2 * fixed / c));
+__device__ __forceinline__ float edge_min(float a, float b2, float c, float inv_c, float fixed, float lo, float hi) {
+    // min over t in [lo,hi] of a*fixed^2 + b2*fixed*t + c*t^2   (b2 = 2B).  The minimiser only needs to be
+    // approximately right (the value is evaluated exactly at it; the error is second order), so 1/c is v_rcp_f32.
+    const float t = fminf(hi, fmaxf(lo, -0.5f * b2 * fixed * inv_c));
     return a * fixed * fixed + (b2 * fixed + c * t) * t;
 }
 __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1, float sx, float sy) {
@@ -236,10 +237,11 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
     const bool in_x = x0 <= 0.0f && x1 >= 0.0f, in_y = y0 <= 0.0f && y1 >= 0.0f;
     if (in_x && in_y) return true;
     const float A = r1.x, B2 = 2.0f * r1.y, C = r1.z;
-    float fmin_ = edge_min(A, B2, C, x0, y0, y1);
-    fmin_ = fminf(fmin_, edge_min(A, B2, C, x1, y0, y1));
-    fmin_ = fminf(fmin_, edge_min(C, B2, A, y0, x0, x1));
-    fmin_ = fminf(fmin_, edge_min(C, B2, A, y1, x0, x1));
+    const float inv_a = __builtin_amdgcn_rcpf(A), inv_c = __builtin_amdgcn_rcpf(C);
+    float fmin_ = edge_min(A, B2, C, inv_c, x0, y0, y1);
+    fmin_ = fminf(fmin_, edge_min(A, B2, C, inv_c, x1, y0, y1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y0, x0, x1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y1, x0, x1));
     return fmin_ <= tau * 1.002f + 0.02f;
 }
 

@@ -49,7 +49,6 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     __shared__ float4 s_r0[kFwdBatch];
     __shared__ float4 s_r1[kFwdBatch];
     __shared__ float4 s_r2[kFwdBatch];
-    __shared__ uint16_t s_list[4][kFwdBatch];
 
     const int tile = blockIdx.x;
     const int tx = tile % v.gx, ty = tile / v.gx;
@@ -78,34 +77,39 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         __syncthreads();
         const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
         if (__ballot(!done) != 0ull) {
-            int m = 0;
+            // 64 staged entries at a time: one lane tests one entry against this wavefront's 8x8 pixels, the
+            // ballot is a scalar bit mask, and the wavefront walks its set bits -- uniform control flow, the
+            // LDS address of the next record is known without a dependent index load, the body is branch-free.
             for (int c = 0; c < cnt; c += kWave) {
-                const int e = c + lane;
-                const int ec = e < cnt ? e : 0;
-                const bool ok = e < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
-                const uint64_t mask = __ballot(ok);
-                if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
-                m += __popcll(mask);
-            }
-            wave_lds_fence();
-            for (int k = 0; k < m; ++k) {
-                const int e = s_list[wave][k];
-                const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-                if (!done) {
+                const int el = c + lane;
+                const int ec = el < cnt ? el : cnt - 1;
+#ifdef SR_EXP_FWD_NOCULL
+                const bool ok = false;
+#else
+                const bool ok = el < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
+#endif
+                uint64_t m = __ballot(ok);
+#ifdef SR_EXP_FWD_NOLOOP
+                m = 0;
+#endif
+                const uint32_t pos0 = (base - start) + (uint32_t)c + 1u;
+                while (m) {
+                    const int bit = (int)__builtin_ctzll(m);
+                    m &= (m - 1);
+                    const int e = c + bit;
+                    const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                     float G, alpha;
-                    if (pair_alpha(r0.x - pxf, r0.y - pyf, r1, G, alpha)) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < kTStop) {
-                            done = true;
-                        } else {
-                            const float w = alpha * T;
-                            Cr += r2.x * w; Cg += r2.y * w; Cb += r2.z * w; D += r0.w * w;
-                            T = test_T;
-                            last = (base - start) + (uint32_t)e + 1u;
-                        }
-                    }
+                    const bool hit = pair_alpha(r0.x - pxf, r0.y - pyf, r1, G, alpha) && !done;
+                    const float test_T = T * (1.0f - alpha);
+                    const bool stop = hit && (test_T < kTStop);
+                    const bool blend = hit && !stop;
+                    done = done || stop;
+                    const float w = blend ? alpha * T : 0.0f;
+                    Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r0.w, w, D);
+                    T = blend ? test_T : T;
+                    last = blend ? pos0 + (uint32_t)bit : last;
                 }
-                if ((k & 7) == 7 && __ballot(!done) == 0ull) break;
+                if (__ballot(!done) == 0ull) break;
             }
         }
     }
@@ -140,7 +144,6 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     __shared__ float4 s_r2[kBwdBatch];
     __shared__ uint32_t s_inst[kBwdBatch];
     __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
-    __shared__ uint16_t s_list[4][kBwdBatch];
     __shared__ uint32_t s_max[4];
 
     const int tile = blockIdx.x;
@@ -202,73 +205,70 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         }
         __syncthreads();
         if (wmax > top - cnt) {
-            int m = 0;
             for (int c = 0; c < cnt; c += kWave) {
-                const int e = c + lane;
-                const int ec = e < cnt ? e : 0;
-                const bool ok = e < cnt && (top - 1 - e) < wmax && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
-                const uint64_t mask = __ballot(ok);
-                if (ok) s_list[wave][m + __popcll(mask & lt)] = (uint16_t)e;
-                m += __popcll(mask);
-            }
-            wave_lds_fence();
-            // 4 list entries per step: their 4 x 10 per-lane partial sums are reduced together by a butterfly
-            // (v_permlane32_swap, v_permlane16_swap, then 4 DPP steps inside each row of 16 lanes):
-            // 100 cross-lane adds per 4 entries instead of 4 x 60.
-            for (int k0 = 0; k0 < m; k0 += 4) {
-                float pv[4][10];
-                int ent[4];
-                bool any = false;
+                const int el = c + lane;
+                const int ec = el < cnt ? el : cnt - 1;
+                const bool ok = el < cnt && (top - 1 - el) < wmax && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
+                uint64_t m = __ballot(ok);
+                // 4 list entries per step (taken from the scalar bit mask): their 4 x 10 per-lane partial sums
+                // are reduced together by a butterfly (v_permlane32_swap, v_permlane16_swap, then 4 DPP steps
+                // inside each row of 16 lanes): 100 cross-lane adds per 4 entries instead of 4 x 60.
+                while (m) {
+                    float pv[4][10];
+                    int ent[4];
+                    bool any = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool live = (k0 + q) < m;
-                    const int e = live ? (int)s_list[wave][k0 + q] : 0;
-                    ent[q] = live ? e : -1;
-                    const int pos = top - 1 - e;
-                    const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-                    const float dx = r0.x - pxf, dy = r0.y - pyf;
-                    float G = 0.f, alpha = 0.f;
-                    bool contrib = false;
-                    if (live && pos < my_last) contrib = pair_alpha(dx, dy, r1, G, alpha);
+                    for (int q = 0; q < 4; ++q) {
+                        const bool live = m != 0ull;
+                        const int e = live ? c + (int)__builtin_ctzll(m) : 0;
+                        m &= (m - 1);  // stays 0 once empty
+                        ent[q] = live ? e : -1;
+                        const int pos = top - 1 - e;
+                        const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+                        const float dx = r0.x - pxf, dy = r0.y - pyf;
+                        float G, alpha;
+                        const bool contrib = pair_alpha(dx, dy, r1, G, alpha) && live && (pos < my_last);
 #pragma unroll
-                    for (int c = 0; c < 10; ++c) pv[q][c] = 0.f;
-                    if (contrib) {
-                        T = T / (1.0f - alpha);
-                        const float wgt = alpha * T;
-                        const float keep = 1.0f - last_alpha;
-                        acR = last_alpha * lR + keep * acR; lR = r2.x;
-                        acG = last_alpha * lG + keep * acG; lG = r2.y;
-                        acB = last_alpha * lB + keep * acB; lB = r2.z;
-                        acD = last_alpha * lD + keep * acD; lD = r0.w;
-                        acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
-                        float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r0.w - acD) * gD + (1.0f - acA) * gA;
-                        dLa *= T;
-                        last_alpha = alpha;
-                        dLa += (-T_final / (1.0f - alpha)) * bg_dot;
-                        const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
-                        const float sxv = g1 * dx, syv = g1 * dy;
-                        pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
-                        pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
+                        for (int k = 0; k < 10; ++k) pv[q][k] = 0.f;
+                        if (contrib) {
+                            const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
+                            T = T * inv_keep;
+                            const float wgt = alpha * T;
+                            const float keep = 1.0f - last_alpha;
+                            acR = last_alpha * lR + keep * acR; lR = r2.x;
+                            acG = last_alpha * lG + keep * acG; lG = r2.y;
+                            acB = last_alpha * lB + keep * acB; lB = r2.z;
+                            acD = last_alpha * lD + keep * acD; lD = r0.w;
+                            acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
+                            float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r0.w - acD) * gD + (1.0f - acA) * gA;
+                            dLa *= T;
+                            last_alpha = alpha;
+                            dLa += (-T_final * inv_keep) * bg_dot;
+                            const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
+                            const float sxv = g1 * dx, syv = g1 * dy;
+                            pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
+                            pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
+                        }
+                        any = any || contrib;
                     }
-                    any = any || contrib;
-                }
-                if (__ballot(any) == 0ull) continue;
-                float red[10];
+                    if (__ballot(any) == 0ull) continue;
+                    float red[10];
 #pragma unroll
-                for (int c = 0; c < 10; ++c) {
-                    const float z01 = swap32_add(pv[0][c], pv[1][c]);   // lanes 0-31: entry 0, lanes 32-63: entry 1
-                    const float z23 = swap32_add(pv[2][c], pv[3][c]);   // lanes 0-31: entry 2, lanes 32-63: entry 3
-                    float w = swap16_add(z01, z23);                     // rows: 0 -> entry 0, 1 -> entry 2, 2 -> entry 1, 3 -> entry 3
-                    w = dpp_add<0xB1>(w); w = dpp_add<0x4E>(w); w = dpp_add<0x124>(w); w = dpp_add<0x128>(w);
-                    red[c] = w;
-                }
-                const int row = lane >> 4;
-                const int q_of_row = ((row & 1) << 1) | (row >> 1);
-                const int e_mine = q_of_row == 0 ? ent[0] : (q_of_row == 1 ? ent[1] : (q_of_row == 2 ? ent[2] : ent[3]));
-                if ((lane & 15) == 0 && e_mine >= 0) {
-                    s_acc[wave][e_mine][0] = make_float4(red[0], red[1], red[2], red[3]);
-                    s_acc[wave][e_mine][1] = make_float4(red[4], red[5], red[6], red[7]);
-                    s_acc[wave][e_mine][2] = make_float4(red[8], red[9], 0.f, 0.f);
+                    for (int k = 0; k < 10; ++k) {
+                        const float z01 = swap32_add(pv[0][k], pv[1][k]);   // lanes 0-31: entry 0, lanes 32-63: entry 1
+                        const float z23 = swap32_add(pv[2][k], pv[3][k]);   // lanes 0-31: entry 2, lanes 32-63: entry 3
+                        float w = swap16_add(z01, z23);                     // rows: 0 -> entry 0, 1 -> entry 2, 2 -> entry 1, 3 -> entry 3
+                        w = dpp_add<0xB1>(w); w = dpp_add<0x4E>(w); w = dpp_add<0x124>(w); w = dpp_add<0x128>(w);
+                        red[k] = w;
+                    }
+                    const int row = lane >> 4;
+                    const int q_of_row = ((row & 1) << 1) | (row >> 1);
+                    const int e_mine = q_of_row == 0 ? ent[0] : (q_of_row == 1 ? ent[1] : (q_of_row == 2 ? ent[2] : ent[3]));
+                    if ((lane & 15) == 0 && e_mine >= 0) {
+                        s_acc[wave][e_mine][0] = make_float4(red[0], red[1], red[2], red[3]);
+                        s_acc[wave][e_mine][1] = make_float4(red[4], red[5], red[6], red[7]);
+                        s_acc[wave][e_mine][2] = make_float4(red[8], red[9], 0.f, 0.f);
+                    }
                 }
             }
         }

@@ -59,5 +59,5 @@ def test_window_against_c_oracle(hip_device, scene):
         rel = ((a - b).abs() / b.abs().clamp_min(1e-3))
         assert rel.median().item() < 1e-5
         assert (rel > 1e-4).float().mean().item() < 5e-3, k  # both fp32: a few pixels flip a threshold decision
-        assert rel.max().item() < 0.05
+        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
     assert torch.equal(o1["radii"], ref["radii"])

@@ -201,6 +201,8 @@ def test_large_image_global_atomic_fallback(hip_device):
     assert torch.equal(out["radii"], cout["radii"])
     for k in ("color", "depth", "alpha"):
         rel = (out[k].double() - cout[k].double()).abs() / cout[k].double().abs().clamp_min(1e-3)
-        assert (rel > 1e-4).float().mean().item() < 1e-4 and rel.max().item() < 0.05, k
+        assert (rel > 1e-4).float().mean().item() < 1e-4, k  # both fp32: a few pixels flip one threshold decision,
+        # which moves them by at most alpha_min * value: 1/255 for colour/alpha, depth/255 for depth
+        assert (out[k].double() - cout[k].double()).abs().max().item() <= 2e-2 * max(1.0, cout[k].abs().max().item()), k
     for k in cg:
         assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
