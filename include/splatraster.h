@@ -108,6 +108,19 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
                       long long instances, void* image, float* out_color, float* out_depth,
                       float* out_alpha, void* hip_stream);
 
+/* Both forward stages in one call WITHOUT draining the pipeline: stage 1 is launched, the instance count is
+ * copied to pinned host memory asynchronously, stage 2 is launched right behind it for a binning buffer sized
+ * for `binning_capacity` instances (every stage-2 kernel exits immediately if the count exceeds it), and only
+ * then does the host wait -- for the early copy, while the GPU keeps running stage 2.
+ * Returns 0 when the count fits (outputs valid), SR_NEED_CAPACITY when it does not: the caller then allocates
+ * sr_binning_bytes(*instances_out) and calls sr_forward_render with instances = *instances_out.
+ * The binning buffer is carved for the capacity it was rendered with; pass that same number as `instances`
+ * to sr_backward. */
+#define SR_NEED_CAPACITY 2
+int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
+               long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,
+               long long* instances_out, void* hip_stream);
+
 /* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero). */
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
                 long long instances, const void* image, const int* radii, const float* dL_dcolor,

@@ -45,6 +45,8 @@ SYMBOLS = {
                                      C.POINTER(C.c_longlong), C.c_void_p]),
     "sr_forward_render": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_forward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
     "sr_backward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrGrads),
                               C.c_void_p]),
@@ -55,6 +57,7 @@ SYMBOLS = {
 }
 
 PROFILE_STAGES = 7
+SR_NEED_CAPACITY = 2
 _lib = None
 
 

@@ -34,6 +34,23 @@ struct StageTimer {
     ~StageTimer() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
 };
 
+// Pinned word + event per device for the asynchronous instance-count read-back of sr_forward
+// (the only state the library keeps; created lazily, a few bytes per device).
+struct HostSync { uint32_t* pinned = nullptr; hipEvent_t ev = nullptr; };
+HostSync g_sync[64];
+
+int get_host_sync(HostSync** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail("hipGetDevice failed");
+    HostSync& h = g_sync[dev];
+    if (!h.pinned) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+        if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    }
+    *out = &h;
+    return 0;
+}
+
 #define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
 int after_launch(const SrView* view, hipStream_t st, const char* what) {
@@ -92,6 +109,33 @@ size_t sr_binning_bytes(long long r, int, int) { return sr::carve_binning(nullpt
 size_t sr_image_bytes(int h, int w) { return sr::carve_image(nullptr, h, w, nullptr); }
 size_t sr_backward_scratch_bytes(long long r) { return sr::align_up((size_t)(r > 0 ? r : 1) * sr::kSlotFloats * sizeof(float), 256); }
 
+}  // extern "C"
+
+namespace {
+
+int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, int* radii, hipStream_t st) {
+    { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
+    SR_TRY(after_launch(view, st, "preprocess"));
+    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, st); }
+    SR_TRY(after_launch(view, st, "scan"));
+    return 0;
+}
+
+int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, const sr::Binning& b,
+                  const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, hipStream_t st) {
+    { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
+    SR_TRY(after_launch(view, st, "emit"));
+    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, st); }
+    SR_TRY(after_launch(view, st, "sort_tiles"));
+    { StageTimer t_(4, st); sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st); }
+    SR_TRY(after_launch(view, st, "render_forward"));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
 int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, int* radii,
                        long long* instances_out, void* hip_stream) {
     SR_TRY(validate(view, splats));
@@ -101,15 +145,38 @@ int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, i
     const sr::SplatsK s = make_splats(splats);
     sr::Geom g;
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
-    { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
-    SR_TRY(after_launch(view, st, "preprocess"));
-    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, st); }
-    SR_TRY(after_launch(view, st, "scan"));
-    uint32_t total = 0;
-    SR_TRY(check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(launch_stage1(view, v, s, g, radii, st));
+    HostSync* hs = nullptr;
+    SR_TRY(get_host_sync(&hs));
+    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
     SR_TRY(check_hip(hipStreamSynchronize(st), "sync after prepare"));
-    *instances_out = (long long)total;
+    *instances_out = (long long)hs->pinned[0];
     return 0;
+}
+
+int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
+               long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,
+               long long* instances_out, void* hip_stream) {
+    SR_TRY(validate(view, splats));
+    if (!geom || !binning || !image || !out_color || !out_depth || !instances_out || (splats->count > 0 && !radii)) return fail("null buffer");
+    if (binning_capacity < 0 || binning_capacity >= (1ll << 32)) return fail("binning capacity out of range");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::ViewK v = make_view(view);
+    const sr::SplatsK s = make_splats(splats);
+    sr::Geom g; sr::Binning b; sr::Image im;
+    sr::carve_geom(geom, s.N, v.H, v.W, &g);
+    sr::carve_binning(binning, binning_capacity, &b);
+    sr::carve_image(image, v.H, v.W, &im);
+    HostSync* hs = nullptr;
+    SR_TRY(get_host_sync(&hs));
+    SR_TRY(launch_stage1(view, v, s, g, radii, st));
+    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
+    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, st));
+    SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));  // the GPU is already running stage 2
+    const long long total = (long long)hs->pinned[0];
+    *instances_out = total;
+    return total > binning_capacity ? SR_NEED_CAPACITY : 0;
 }
 
 int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, void* binning,
@@ -125,13 +192,7 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     sr::carve_binning(binning, instances, &b);
     sr::carve_image(image, v.H, v.W, &im);
-    { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
-    SR_TRY(after_launch(view, st, "emit"));
-    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, st); }
-    SR_TRY(after_launch(view, st, "sort_tiles"));
-    { StageTimer t_(4, st); sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st); }
-    SR_TRY(after_launch(view, st, "render_forward"));
-    return 0;
+    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, st);
 }
 
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     __shared__ ushort4 s_rect[kBlock];
     __shared__ uint32_t s_depth[kBlock];
     __shared__ uint32_t s_scan[8];
+    if (g.total[0] > b.capacity) return;  // binning buffer too small: the host re-runs stage 2 with a larger one
     int sb0 = blockIdx.x, sb1 = blockIdx.x + 1;
     if constexpr (MATRIX) {
         sb0 = blockIdx.x * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
@@ -222,6 +223,7 @@ template <int CAP, int THREADS, int MINLEN>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles(const Geom g, const Binning b) {
     __shared__ uint64_t skey[CAP];
     __shared__ uint32_t sval[CAP];
+    if (g.total[0] > b.capacity) return;
     const uint32_t tile = blockIdx.x;
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
@@ -249,6 +251,7 @@ template <int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b) {
     __shared__ uint64_t skey[CAP];
     __shared__ uint32_t sval[CAP];
+    if (g.total[0] > b.capacity) return;
     const uint32_t tile = blockIdx.x;
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;

@@ -77,6 +77,7 @@ struct Binning {
     uint32_t* vals_tmp;  // [R]
     uint32_t* sorted_id;   // [R] splat index, per tile front-to-back
     uint32_t* sorted_inst; // [R] instance index (slot of the backward scratch)
+    uint32_t capacity;     // instances the arrays above were carved for; stage-2 kernels exit if total > capacity
 };
 
 struct Image {
@@ -130,6 +131,7 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     t.keys = c.take<uint64_t>(r); t.vals = c.take<uint32_t>(r);
     t.keys_tmp = c.take<uint64_t>(r); t.vals_tmp = c.take<uint32_t>(r);
     t.sorted_id = c.take<uint32_t>(r); t.sorted_inst = c.take<uint32_t>(r);
+    t.capacity = (uint32_t)(R > 0 ? R : 0);
     if (b) *b = t;
     return align_up(c.off, 256);
 }

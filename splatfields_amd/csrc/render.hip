@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     __shared__ float4 s_r1[kFwdBatch];
     __shared__ float4 s_r2[kFwdBatch];
 
+    if (g.total[0] > b.capacity) return;  // uniform: see sr_forward
     const int tile = blockIdx.x;
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = wave_id(), lane = lane_id();

@@ -40,6 +40,10 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 LAST_INSTANCES = 0  # tile-splat instances of the most recent forward (diagnostics / bench)
+# Per-device estimate of the instance count used to size the binning buffer BEFORE the count is known, so that
+# the forward never drains the GPU pipeline (include/splatraster.h: sr_forward).  Grows on demand.
+_CAPACITY = {}
+_CAPACITY_HEADROOM = 1.25
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -135,15 +139,26 @@ class _RasterizeGaussians(torch.autograd.Function):
             geom = torch.empty(lib.sr_geom_bytes(n, H, W), dtype=torch.uint8, device=dev)
             image = torch.empty(lib.sr_image_bytes(H, W), dtype=torch.uint8, device=dev)
             inst = C.c_longlong(0)
-            _lib.check(lib.sr_forward_prepare(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii),
-                                              C.byref(inst), stream))
+            key = (dev.index, n, H, W)
+            capacity = _CAPACITY.get(key) or max(4 * n, 1 << 16)
+            binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
+            status = lib.sr_forward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
+                                    capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), C.byref(inst), stream)
             instances = int(inst.value)
-            binning = torch.empty(lib.sr_binning_bytes(instances, H, W), dtype=torch.uint8, device=dev)
-            _lib.check(lib.sr_forward_render(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning),
-                                             instances, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), stream))
+            if status == _lib.SR_NEED_CAPACITY:
+                # first call for this size, or the cloud grew: re-run stage 2 with a buffer that fits
+                capacity = int(instances * _CAPACITY_HEADROOM) + 1024
+                binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
+                _lib.check(lib.sr_forward_render(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning),
+                                                 capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), stream))
+            else:
+                _lib.check(status)
+            _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(instances * _CAPACITY_HEADROOM) + 1024)
         global LAST_INSTANCES
         LAST_INSTANCES = instances
         ctx.instances = instances
+        ctx.capacity = capacity
+        ctx.view_pack = view
         ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image)
         return color, radii, depth, alpha
 
@@ -162,7 +177,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
         grad_depth, grad_alpha = g(grad_depth), g(grad_alpha)
-        view = _ViewPack(rs, dev, ctx.sh_coeffs)
+        view = ctx.view_pack  # camera tensors were made contiguous in forward
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         d_means3D, d_means2D, d_opac = new(n, 3), new(n, 3), new(n, 1)
         d_sc = new(n, 3) if sc is not None else None
@@ -176,7 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.instances), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col))
-            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.instances,
+            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
                                        _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
                                        _ptr(scratch), C.byref(grads), stream))
         # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings
