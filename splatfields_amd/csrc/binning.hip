@@ -220,24 +220,27 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
 
 // One workgroup per tile; handles list lengths in (MINLEN, CAP].
 template <int CAP, int THREADS, int MINLEN>
-__global__ void __launch_bounds__(THREADS) k_sort_tiles(const Geom g, const Binning b) {
+__global__ void __launch_bounds__(THREADS) k_sort_tiles(const Geom g, const Binning b, int n_tiles) {
     __shared__ uint64_t skey[CAP];
     __shared__ uint32_t sval[CAP];
     if (g.total[0] > b.capacity) return;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t start = g.tile_start[tile];
-    const uint32_t n = g.tile_start[tile + 1] - start;
-    if (n <= (uint32_t)MINLEN || n > (uint32_t)CAP) return;
-    const uint32_t n2 = next_pow2(n);
-    for (uint32_t i = threadIdx.x; i < n2; i += THREADS) {
-        skey[i] = i < n ? b.keys[start + i] : ~0ull;
-        sval[i] = i < n ? b.vals[start + i] : 0u;
-    }
-    __syncthreads();
-    bitonic_lds<THREADS>(skey, sval, n2);
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        b.sorted_id[start + i] = sval[i];
-        b.sorted_inst[start + i] = (uint32_t)skey[i];
+    // rare class: a small grid strides over the tiles instead of launching one (mostly idle) workgroup per tile
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
+        const uint32_t start = g.tile_start[tile];
+        const uint32_t n = g.tile_start[tile + 1] - start;
+        if (n <= (uint32_t)MINLEN || n > (uint32_t)CAP) continue;
+        const uint32_t n2 = next_pow2(n);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n2; i += THREADS) {
+            skey[i] = i < n ? b.keys[start + i] : ~0ull;
+            sval[i] = i < n ? b.vals[start + i] : 0u;
+        }
+        __syncthreads();
+        bitonic_lds<THREADS>(skey, sval, n2);
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+            b.sorted_id[start + i] = sval[i];
+            b.sorted_inst[start + i] = (uint32_t)skey[i];
+        }
     }
 }
 
@@ -248,14 +251,15 @@ template <typename T>
 __device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int CAP, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b) {
+__global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b, int n_tiles) {
     __shared__ uint64_t skey[CAP];
     __shared__ uint32_t sval[CAP];
     if (g.total[0] > b.capacity) return;
-    const uint32_t tile = blockIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
-    if (n <= (uint32_t)CAP) return;
+    if (n <= (uint32_t)CAP) continue;
+    __syncthreads();
     uint64_t* k0 = b.keys + start; uint32_t* v0 = b.vals + start;
     uint64_t* k1 = b.keys_tmp + start; uint32_t* v1 = b.vals_tmp + start;
     for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
@@ -297,15 +301,187 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
         b.sorted_id[start + i] = ld_agent(v0 + i);
         b.sorted_inst[start + i] = (uint32_t)ld_agent(k0 + i);
     }
+    }  // tile loop
+}
+
+// ---- register-resident bitonic network (the default path for lists up to 4096 entries) ---------------------
+// 256 threads, E consecutive elements per thread (N = 256*E).  A compare-exchange at distance j is
+//   j < E        : inside one thread's registers,
+//   j < 64*E     : with lane (lane ^ j/E) of the same wavefront through a cross-lane shuffle,
+//   otherwise    : with another wavefront through LDS -- exactly 3 such stages for every N.
+// The LDS-only network above moves all 12 bytes/entry through LDS log2(N)(log2(N)+1)/2 times (55 for N=1024)
+// and was LDS-bandwidth bound (rocprofv3: SQ_WAIT_INST_LDS dominant); this one touches LDS 3 times.
+template <int E>
+__device__ __forceinline__ void exchange_select(uint64_t& k, uint32_t& v, uint64_t pk, uint32_t pv, bool keep_min) {
+    // keys are unique except for the +inf padding, where either choice is fine: one compare, mask xnor, 3 selects
+    const bool take = (pk < k) == keep_min;
+    k = take ? pk : k;
+    v = take ? pv : v;
+}
+
+template <int N, int E>
+__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint64_t* skey, uint32_t* sval) {
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const uint32_t i = tid * E + e;
+                        const bool asc = (i & kk) == 0;
+                        const bool swap = (k[e] > k[e | j]) == asc;
+                        const uint64_t ka = k[e], kb = k[e | j];
+                        const uint32_t va = v[e], vb = v[e | j];
+                        k[e] = swap ? kb : ka; k[e | j] = swap ? ka : kb;
+                        v[e] = swap ? vb : va; v[e | j] = swap ? va : vb;
+                    }
+                }
+            } else if (j < 64 * E) {
+                const int d = j / E;
+                const bool lower = (tid & d) == 0;
+                // kk >= 2j > E here, so the direction bit (i & kk) depends on the thread only
+                const bool keep_min = lower == (((tid * E) & kk) == 0);
+                const int src = (int)((tid ^ (uint32_t)d) & 63u) << 2;
+                uint32_t plo[E], phi[E], pv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {  // all shuffles of the stage in flight before the first use
+                    plo[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)k[e]);
+                    phi[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(k[e] >> 32));
+                    pv[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) exchange_select<E>(k[e], v[e], ((uint64_t)phi[e] << 32) | plo[e], pv[e], keep_min);
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) { skey[tid * E + e] = k[e]; sval[tid * E + e] = v[e]; }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const uint32_t i = tid * E + e;
+                    const bool asc = (i & kk) == 0;
+                    const bool lower = (i & j) == 0;
+                    exchange_select<E>(k[e], v[e], skey[i ^ j], sval[i ^ j], lower == asc);
+                }
+            }
+        }
+    }
+}
+
+// Loads up to N = 256*E consecutive entries (padding with +inf keys), sorts them in registers; afterwards
+// thread t holds the entries of rank t*E .. t*E+E-1.
+template <int N, int E>
+__device__ __forceinline__ void load_sort_chunk(const Binning& b, uint32_t first, uint32_t m, uint64_t (&k)[E], uint32_t (&v)[E],
+                                                uint64_t* scratch_key, uint32_t* scratch_val) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = threadIdx.x * E + e;
+        k[e] = i < m ? b.keys[first + i] : ~0ull;
+        v[e] = i < m ? b.vals[first + i] : 0u;
+    }
+    bitonic_regs<N, E>(k, v, scratch_key, scratch_val);
+}
+
+template <int N, int E>
+__device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start, uint32_t n, uint64_t* skey, uint32_t* sval) {
+    uint64_t k[E];
+    uint32_t v[E];
+    load_sort_chunk<N, E>(b, start, n, k, v, skey, sval);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = threadIdx.x * E + e;
+        if (i < n) { b.sorted_id[start + i] = v[e]; b.sorted_inst[start + i] = (uint32_t)k[e]; }
+    }
+}
+
+template <int N, int E>
+__device__ __forceinline__ void sort_chunk_to_lds(const Binning& b, uint32_t first, uint32_t m, uint64_t* run_key, uint32_t* run_val,
+                                                  uint64_t* scratch_key, uint32_t* scratch_val) {
+    uint64_t k[E];
+    uint32_t v[E];
+    load_sort_chunk<N, E>(b, first, m, k, v, scratch_key, scratch_val);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = threadIdx.x * E + e;
+        if (i < m) { run_key[i] = k[e]; run_val[i] = v[e]; }
+    }
+}
+
+// lists of 1..1024 entries: one register network, one workgroup (256 threads) per tile, LDS 12 KiB
+__global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Binning b) {
+    __shared__ uint64_t skey[1024];
+    __shared__ uint32_t sval[1024];
+    if (g.total[0] > b.capacity) return;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t start = g.tile_start[tile];
+    const uint32_t n = g.tile_start[tile + 1] - start;
+    if (n == 0u || n > 1024u) return;
+    if (n <= 256u) sort_tile_regs<256, 1>(b, start, n, skey, sval);
+    else if (n <= 512u) sort_tile_regs<512, 2>(b, start, n, skey, sval);
+    else sort_tile_regs<1024, 4>(b, start, n, skey, sval);
+}
+
+// lists of (LO, CAP] entries: runs of 1024 sorted by the register network into LDS, then ONE multi-way merge pass --
+// keys are unique, so the final position of an entry is its index in its own run plus, for every other run, the
+// number of smaller keys there (binary search in LDS).  A list of 1100 entries costs a 1024- and a 256-network
+// instead of the 2048-network a power-of-two bitonic sort would need.
+template <int LO, int CAP>
+__global__ void __launch_bounds__(256) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);                 // [CAP]
+    uint64_t* scratch_key = run_key + CAP;                                  // [1024]
+    uint32_t* run_val = reinterpret_cast<uint32_t*>(scratch_key + 1024);    // [CAP]
+    uint32_t* scratch_val = run_val + CAP;                                  // [1024]
+    if (g.total[0] > b.capacity) return;
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
+        const uint32_t start = g.tile_start[tile];
+        const uint32_t n = g.tile_start[tile + 1] - start;
+        if (n <= (uint32_t)LO || n > (uint32_t)CAP) continue;
+        const uint32_t n_runs = (n + 1023u) / 1024u;
+        for (uint32_t r = 0; r < n_runs; ++r) {
+            const uint32_t m = min(1024u, n - r * 1024u);
+            __syncthreads();  // scratch reuse
+            if (m <= 256u) sort_chunk_to_lds<256, 1>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
+            else if (m <= 512u) sort_chunk_to_lds<512, 2>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
+            else sort_chunk_to_lds<1024, 4>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t own = i >> 10;
+            const uint64_t key = run_key[i];
+            uint32_t rank = i & 1023u;
+            for (uint32_t r = 0; r < n_runs; ++r) {
+                if (r == own) continue;
+                const uint64_t* rk = run_key + r * 1024u;
+                uint32_t lo = 0, hi = min(1024u, n - r * 1024u);
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk[mid] < key) lo = mid + 1; else hi = mid; }
+                rank += lo;
+            }
+            b.sorted_id[start + rank] = run_val[i];
+            b.sorted_inst[start + rank] = (uint32_t)key;
+        }
+        __syncthreads();
+    }
 }
 
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    hipLaunchKernelGGL((k_sort_tiles<1024, 256, 0>), dim3(tiles), dim3(256), 0, st, g, b);
-    hipLaunchKernelGGL((k_sort_tiles<4096, 512, 1024>), dim3(tiles), dim3(512), 0, st, g, b);
-    hipLaunchKernelGGL((k_sort_tiles<8192, 1024, 4096>), dim3(tiles), dim3(1024), 0, st, g, b);
-    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(tiles), dim3(1024), 0, st, g, b);
+    auto lds = [](int cap) { return (size_t)(cap + 1024) * 12; };
+    hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
+    hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048>), dim3(tiles), dim3(256), lds(2048), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096>), dim3(tiles), dim3(256), lds(4096), st, g, b, tiles);
+    const int rare_grid = tiles < 128 ? tiles : 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192>), dim3(rare_grid), dim3(256), lds(8192), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(rare_grid), dim3(1024), 0, st, g, b, tiles);
 }
 
 }  // namespace sr
