@@ -32,6 +32,8 @@ def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_de
     t_small = timed((0, y0, gx, y0 + rows))
     scale = max(1.0, target_seconds / max(t_small, 1e-3))
     rows_full = int(min(gy, max(rows, math.floor(rows * scale * 0.8))))
+    if rows_full >= gy - 2:
+        rows_full = gy  # the whole image fits the budget
     y0 = (gy - rows_full) // 2
     window = (0, y0, gx, y0 + rows_full)
     t = timed(window)
