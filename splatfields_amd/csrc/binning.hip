@@ -311,6 +311,43 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
 //   otherwise    : with another wavefront through LDS -- exactly 3 such stages for every N.
 // The LDS-only network above moves all 12 bytes/entry through LDS log2(N)(log2(N)+1)/2 times (55 for N=1024)
 // and was LDS-bandwidth bound (rocprofv3: SQ_WAIT_INST_LDS dominant); this one touches LDS 3 times.
+// Value of lane (lane ^ D) without touching LDS (ds_bpermute_b32 measured at ~24 cycles per wave-instruction
+// per SIMD on MI355X, DPP adds/moves at ~4, v_permlane*_swap at ~8):
+//   D = 1, 2 : DPP quad_perm          D = 8 : DPP row_ror:8 (rotation by 8 in a row of 16 is xor 8)
+//   D = 4    : row_ror:4 for lanes with bit 2 set, row_ror:12 for the others
+//   D = 16/32: v_permlane16_swap / v_permlane32_swap of the value with itself, then pick the swapped half
+template <int D>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);
+    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);
+    else if constexpr (D == 4) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);  // from lane-4 (mod 16)
+        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x12C, 0xf, 0xf, false);  // from lane+4 (mod 16)
+        return (threadIdx.x & 4u) ? a : b;
+    } else if constexpr (D == 16) {
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r.x rows = (x0,x0,x2,x2), r.y rows = (x1,x1,x3,x3)
+        return (threadIdx.x & 16u) ? r.x : r.y;
+    } else {
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        const u2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r.x = (lo,lo), r.y = (hi,hi)
+        return (threadIdx.x & 32u) ? r.x : r.y;
+    }
+}
+
+// d is a compile-time constant after the network loops are unrolled; the dead branches fold away
+__device__ __forceinline__ uint32_t lane_xor_d(uint32_t x, int d) {
+    switch (d) {
+        case 1: return lane_xor<1>(x);
+        case 2: return lane_xor<2>(x);
+        case 4: return lane_xor<4>(x);
+        case 8: return lane_xor<8>(x);
+        case 16: return lane_xor<16>(x);
+        default: return lane_xor<32>(x);
+    }
+}
+
 template <int E>
 __device__ __forceinline__ void exchange_select(uint64_t& k, uint32_t& v, uint64_t pk, uint32_t pv, bool keep_min) {
     // keys are unique except for the +inf padding, where either choice is fine: one compare, mask xnor, 3 selects
@@ -344,13 +381,12 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E],
                 const bool lower = (tid & d) == 0;
                 // kk >= 2j > E here, so the direction bit (i & kk) depends on the thread only
                 const bool keep_min = lower == (((tid * E) & kk) == 0);
-                const int src = (int)((tid ^ (uint32_t)d) & 63u) << 2;
                 uint32_t plo[E], phi[E], pv[E];
 #pragma unroll
-                for (int e = 0; e < E; ++e) {  // all shuffles of the stage in flight before the first use
-                    plo[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)k[e]);
-                    phi[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(k[e] >> 32));
-                    pv[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v[e]);
+                for (int e = 0; e < E; ++e) {
+                    plo[e] = lane_xor_d((uint32_t)k[e], d);
+                    phi[e] = lane_xor_d((uint32_t)(k[e] >> 32), d);
+                    pv[e] = lane_xor_d(v[e], d);
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) exchange_select<E>(k[e], v[e], ((uint64_t)phi[e] << 32) | plo[e], pv[e], keep_min);

@@ -229,12 +229,12 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         const float dx = r0.x - pxf, dy = r0.y - pyf;
                         float G, alpha;
                         const bool contrib = pair_alpha(dx, dy, r1, G, alpha) && live && (pos < my_last);
-#pragma unroll
-                        for (int k = 0; k < 10; ++k) pv[q][k] = 0.f;
+                        // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
+                        float g1 = 0.f, wgt = 0.f;
                         if (contrib) {
                             const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
                             T = T * inv_keep;
-                            const float wgt = alpha * T;
+                            wgt = alpha * T;
                             const float keep = 1.0f - last_alpha;
                             acR = last_alpha * lR + keep * acR; lR = r2.x;
                             acG = last_alpha * lG + keep * acG; lG = r2.y;
@@ -245,11 +245,11 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                             dLa *= T;
                             last_alpha = alpha;
                             dLa += (-T_final * inv_keep) * bg_dot;
-                            const float g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
-                            const float sxv = g1 * dx, syv = g1 * dy;
-                            pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
-                            pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
+                            g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
                         }
+                        const float sxv = g1 * dx, syv = g1 * dy;
+                        pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
+                        pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
                         any = any || contrib;
                     }
                     if (__ballot(any) == 0ull) continue;
