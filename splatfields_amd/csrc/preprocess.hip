@@ -94,6 +94,35 @@ __device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
 // (rows padded to 13 float4 = 208 B) instead of 48 strided 4-byte accesses per lane.
 constexpr int kShRowF4 = 13;
 
+// 256 splats x 12 float4: every thread moves 12 float4, all 12 global loads issued before the first LDS write
+// (the naive loop compiled to load -> s_waitcnt vmcnt(0) -> ds_write per iteration: one load in flight per lane).
+__device__ __forceinline__ void stage_sh_in(float4* s_sh, const float* shs, size_t first_splat, int n_here) {
+    const float4* src = reinterpret_cast<const float4*>(shs + first_splat * 48);
+    const int total = n_here * 12;
+    float4 tmp[12];
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int i = it * kBlock + (int)threadIdx.x;
+        tmp[it] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int i = it * kBlock + (int)threadIdx.x;
+        const int sp = i / 12;
+        if (i < total) s_sh[sp * kShRowF4 + (i - sp * 12)] = tmp[it];
+    }
+}
+__device__ __forceinline__ void stage_sh_out(const float4* s_sh, float* dst_base, size_t first_splat, int n_here) {
+    float4* dst = reinterpret_cast<float4*>(dst_base + first_splat * 48);
+    const int total = n_here * 12;
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int i = it * kBlock + (int)threadIdx.x;
+        const int sp = i / 12;
+        if (i < total) dst[i] = s_sh[sp * kShRowF4 + (i - sp * 12)];
+    }
+}
+
 template <bool STAGE_SH, bool COUNT_ATOMIC>
 __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
     __shared__ uint32_t s_off[COUNT_ATOMIC ? kBlock + 1 : 1];
@@ -107,21 +136,27 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     uint32_t touched = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
 
+    // issue this splat's own loads first, then the staged SH block: everything is in flight together
+    float3 p = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float opac_in = 0.f;
+    if (idx < s.N) {
+        p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
+        opac_in = s.opacities[idx];
+        if (!s.cov3D) {
+            q_in = reinterpret_cast<const float4*>(s.rotations)[idx];
+            sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
+        }
+    }
     if constexpr (STAGE_SH) {
         const size_t first = (size_t)blockIdx.x * kBlock;
-        const int n_here = min(kBlock, s.N - (int)first);
-        const float4* src = reinterpret_cast<const float4*>(s.shs + first * 48);
-        for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
-            const int sp = i / 12;
-            s_sh[sp * kShRowF4 + (i - sp * 12)] = src[i];
-        }
+        stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
         __syncthreads();
     }
 
     if (idx < s.N) {
         int out_radius = 0;
         uint8_t flags = 0;
-        const float3 p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
         const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
                                       vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13],
                                       vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14]);
@@ -138,10 +173,9 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                 S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
             } else {
                 float R[9];
-                const float4 q = reinterpret_cast<const float4*>(s.rotations)[idx];
-                quat_to_rot(q, R);
+                quat_to_rot(q_in, R);
                 const float m = v.scale_modifier;
-                S = cov3d_from(make_float3(m * s.scales[3 * idx], m * s.scales[3 * idx + 1], m * s.scales[3 * idx + 2]), R);
+                S = cov3d_from(make_float3(m * sc_in.x, m * sc_in.y, m * sc_in.z), R);
             }
             const Ewa e = ewa_setup(pv, v, vm);
             if (e.clamp_x) flags |= kFlagClampTx;
@@ -166,7 +200,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                 const int uymax = min(v.gy, max(0, (int)((py + my_radius + kTile - 1) / kTile)));
                 if ((uxmax - uxmin) * (uymax - uymin) > 0) {
                     out_radius = (int)my_radius;
-                    const float opac = s.opacities[idx];
+                    const float opac = opac_in;
                     // exact support of alpha >= 1/255:  d^T Q d <= 2 ln(255 o)  ->  |dx| <= sqrt(tau * a)
                     float ex = -1.0f, ey = -1.0f;
                     const float tau = 2.0f * __logf(255.0f * opac);
@@ -277,15 +311,27 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = idx < s.N;
     const bool stage_read = STAGE_SH && v.sh_degree >= 2;
+    // this splat's own loads are issued before the staged SH block so that everything is in flight together
+    int radius_in = 0;
+    uint32_t first_in = 0, cnt_in = 0;
+    uint8_t flags_in = 0;
+    float4 r1_in = make_float4(0.f, 0.f, 0.f, 0.f), q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float3 p_in = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
+    if (valid) {
+        radius_in = radii[idx];
+        first_in = g.offsets[idx]; cnt_in = g.touched[idx];
+        flags_in = g.flags[idx];
+        r1_in = g.rec[4 * (size_t)idx + 1];
+        p_in = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
+        if (!s.cov3D) {
+            q_in = reinterpret_cast<const float4*>(s.rotations)[idx];
+            sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
+        }
+    }
     if constexpr (STAGE_SH) {
         if (stage_read) {
             const size_t first = (size_t)blockIdx.x * kBlock;
-            const int n_here = min(kBlock, s.N - (int)first);
-            const float4* src = reinterpret_cast<const float4*>(s.shs + first * 48);
-            for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
-                const int sp = i / 12;
-                s_sh[sp * kShRowF4 + (i - sp * 12)] = src[i];
-            }
+            stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
         }
         __syncthreads();
     }
@@ -301,14 +347,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     float2 d_m2d = make_float2(0.f, 0.f);
     float3 d_rgb = make_float3(0.f, 0.f, 0.f);
     float d_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool visible = radii[idx] > 0;
+    const bool visible = radius_in > 0;
 
     float3 p = make_float3(0.f, 0.f, 0.f);
     uint8_t flags = 0;
     if (visible) {
         // ---- segmented reduction of this splat's instance slots (deterministic order) ----
         float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dd = 0.f;
-        const uint32_t first = g.offsets[idx], cnt = g.touched[idx];
+        const uint32_t first = first_in, cnt = cnt_in;
         const float4* sl = reinterpret_cast<const float4*>(slots) + (size_t)first * 3;
         for (uint32_t k = 0; k < cnt; ++k) {
             const float4 a = sl[3 * k], b = sl[3 * k + 1], c = sl[3 * k + 2];
@@ -316,8 +362,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             Sxy += b.x; Syy += b.y; dr += b.z; dg += b.w;
             db += c.x; dd += c.y;
         }
-        flags = g.flags[idx];
-        const float4 r1 = g.rec[4 * (size_t)idx + 1];
+        flags = flags_in;
+        const float4 r1 = r1_in;
         const float A = r1.x, B = r1.y, C = r1.z, o = r1.w;
         d_opac = S0;
         d_rgb = make_float3(dr, dg, db);
@@ -327,7 +373,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         // conic gradients; .y is half of the true dL/dB (off-diagonal counted once, used twice below)
         const float dcon_x = -0.5f * o * Sxx, dcon_y = -0.5f * o * Sxy, dcon_z = -0.5f * o * Syy;
 
-        p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
+        p = p_in;
         const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
                                       vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13],
                                       vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14]);
@@ -339,10 +385,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const float* c = s.cov3D + 6 * (size_t)idx;
             S.xx = c[0]; S.xy = c[1]; S.xz = c[2]; S.yy = c[3]; S.yz = c[4]; S.zz = c[5];
         } else {
-            q = reinterpret_cast<const float4*>(s.rotations)[idx];
+            q = q_in;
             quat_to_rot(q, R);
             const float m = v.scale_modifier;
-            sc = make_float3(m * s.scales[3 * idx], m * s.scales[3 * idx + 1], m * s.scales[3 * idx + 2]);
+            sc = make_float3(m * sc_in.x, m * sc_in.y, m * sc_in.z);
             S = cov3d_from(sc, R);
         }
         const Ewa e = ewa_setup(pv, v, vm);
@@ -491,12 +537,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     if constexpr (STAGE_SH) {
         __syncthreads();
         const size_t first = (size_t)blockIdx.x * kBlock;
-        const int n_here = min(kBlock, s.N - (int)first);
-        float4* dst = reinterpret_cast<float4*>(gr.shs + first * 48);
-        for (int i = threadIdx.x; i < n_here * 12; i += kBlock) {
-            const int sp = i / 12;
-            dst[i] = s_sh[sp * kShRowF4 + (i - sp * 12)];
-        }
+        stage_sh_out(s_sh, gr.shs, first, min(kBlock, s.N - (int)first));
     }
 }
 
