@@ -177,8 +177,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
             uint32_t slot;
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
-            b.keys[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(base + i);
-            b.vals[slot] = first_splat + (uint32_t)e;
+            b.ent[slot] = make_uint4(base + i, s_depth[e], first_splat + (uint32_t)e, 0u);
         });
     }
 }
@@ -232,8 +231,9 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles(const Geom g, const Binn
         const uint32_t n2 = next_pow2(n);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n2; i += THREADS) {
-            skey[i] = i < n ? b.keys[start + i] : ~0ull;
-            sval[i] = i < n ? b.vals[start + i] : 0u;
+            const uint4 en = i < n ? b.ent[start + i] : make_uint4(~0u, ~0u, 0u, 0u);
+            skey[i] = ((uint64_t)en.y << 32) | en.x;
+            sval[i] = en.z;
         }
         __syncthreads();
         bitonic_lds<THREADS>(skey, sval, n2);
@@ -266,8 +266,9 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
         const uint32_t m = min((uint32_t)CAP, n - c0);
         const uint32_t m2 = next_pow2(m);
         for (uint32_t i = threadIdx.x; i < m2; i += THREADS) {
-            skey[i] = i < m ? k0[c0 + i] : ~0ull;
-            sval[i] = i < m ? v0[c0 + i] : 0u;
+            const uint4 en = i < m ? b.ent[start + c0 + i] : make_uint4(~0u, ~0u, 0u, 0u);
+            skey[i] = ((uint64_t)en.y << 32) | en.x;
+            sval[i] = en.z;
         }
         __syncthreads();
         bitonic_lds<THREADS>(skey, sval, m2);
@@ -415,8 +416,9 @@ __device__ __forceinline__ void load_sort_chunk(const Binning& b, uint32_t first
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = threadIdx.x * E + e;
-        k[e] = i < m ? b.keys[first + i] : ~0ull;
-        v[e] = i < m ? b.vals[first + i] : 0u;
+        const uint4 en = i < m ? b.ent[first + i] : make_uint4(~0u, ~0u, 0u, 0u);
+        k[e] = ((uint64_t)en.y << 32) | en.x;
+        v[e] = en.z;
     }
     bitonic_regs<N, E>(k, v, scratch_key, scratch_val);
 }

@@ -71,9 +71,11 @@ inline Chunking make_chunking(int N, int tiles) {
 }
 
 struct Binning {
-    uint64_t* keys;      // [R] (depth bits << 32) | instance index, bucketed per tile, unsorted
-    uint32_t* vals;      // [R] splat index
-    uint64_t* keys_tmp;  // [R] ping-pong for the long-list merge path
+    uint4* ent;          // [R] bucketed per tile, unsorted: (key lo = instance index, key hi = depth bits, splat index, 0)
+                         //     -- ONE 16-byte store per instance from the scatter
+    uint64_t* keys;      // [R] ping-pong pair A of the long-list merge path
+    uint32_t* vals;      // [R]
+    uint64_t* keys_tmp;  // [R] ping-pong pair B
     uint32_t* vals_tmp;  // [R]
     uint32_t* sorted_id;   // [R] splat index, per tile front-to-back
     uint32_t* sorted_inst; // [R] instance index (slot of the backward scratch)
@@ -128,6 +130,7 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     Carver c{static_cast<char*>(base), 0};
     const size_t r = (size_t)(R > 0 ? R : 1);
     Binning t;
+    t.ent = c.take<uint4>(r);
     t.keys = c.take<uint64_t>(r); t.vals = c.take<uint32_t>(r);
     t.keys_tmp = c.take<uint64_t>(r); t.vals_tmp = c.take<uint32_t>(r);
     t.sorted_id = c.take<uint32_t>(r); t.sorted_inst = c.take<uint32_t>(r);
