@@ -54,7 +54,10 @@ struct Geom {
     uint32_t* segbase;       // [segments][tiles_padded] exclusive prefix of segtot over segments
 };
 
-constexpr int kMaxChunks = 1024;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
+#ifndef SR_MAX_CHUNKS
+#define SR_MAX_CHUNKS 1024
+#endif
+constexpr int kMaxChunks = SR_MAX_CHUNKS;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
 constexpr int kSegRows = 128;           // chunks per column-scan segment
 constexpr int kMaxMatrixTiles = 16384;  // LDS histogram of 64 KiB; larger images use the global-atomic fallback
 
