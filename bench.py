@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--cpu-baseline", choices=["auto", "none"], default="auto")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded baseline sample")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing the control flow)")
+    p.add_argument("--single-device", action="store_true", help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
     return p.parse_args()
 
 
@@ -76,11 +78,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from splatfields_amd import _lib, rasterizer as rz
     from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -162,7 +167,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom)
+            tj = json.load(open(tpath))
+            same = tj.get("_workload") == {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree}
+            traffic = tj.get(dom) if same else None  # PMC bytes were collected for that workload only
         except Exception:
             traffic = None
 
