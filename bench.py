@@ -118,8 +118,10 @@ def main():
             means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
             shs=params["shs"] if use_sh else None, colors_precomp=None if use_sh else params["colors_precomp"],
             scales=params["scales"], rotations=params["rotations"])
-        loss = (color * gi).sum() + (depth * gd).sum() + (alpha * ga).sum()
-        loss.backward()
+        # loss = sum(color*G_img) + sum(depth*G_depth) + sum(alpha*G_alpha) is linear, so its upstream
+        # gradients are the fixed G tensors: feed them directly instead of spending ~15 small PyTorch kernels
+        # (mul/sum/add and their backward) on a stand-in loss that is not part of the rasterizer.
+        torch.autograd.backward((color, depth, alpha), (gi, gd, ga))
         if world > 1:
             allreduce_gradients(list(params.values()), world)
         if record:
