@@ -121,11 +121,18 @@ int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
     return 0;
 }
 
+// hs != nullptr: the instance count / longest list were copied to hs->pinned and hs->ev recorded; the host waits for
+// them after launching the scatter (the GPU keeps working) and then launches only the sort classes that are needed.
 int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, const sr::Binning& b,
-                  const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, hipStream_t st) {
+                  const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, HostSync* hs, hipStream_t st) {
     { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
     SR_TRY(after_launch(view, st, "emit"));
-    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, st); }
+    long long max_len = -1;
+    if (hs) {
+        SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));
+        max_len = (long long)hs->pinned[1];
+    }
+    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, max_len, st); }
     SR_TRY(after_launch(view, st, "sort_tiles"));
     { StageTimer t_(4, st); sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st); }
     SR_TRY(after_launch(view, st, "render_forward"));
@@ -170,10 +177,9 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
     HostSync* hs = nullptr;
     SR_TRY(get_host_sync(&hs));
     SR_TRY(launch_stage1(view, v, s, g, radii, st));
-    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
     SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
-    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, st));
-    SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));  // the GPU is already running stage 2
+    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, st));  // waits inside, GPU busy
     const long long total = (long long)hs->pinned[0];
     *instances_out = total;
     return total > binning_capacity ? SR_NEED_CAPACITY : 0;
@@ -192,7 +198,7 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     sr::carve_binning(binning, instances, &b);
     sr::carve_image(image, v.H, v.W, &im);
-    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, st);
+    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, st);
 }
 
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
     uint32_t* dst = tiles ? g.tile_start : g.block_offsets;
     const int n = tiles ? n_tiles : n_sub;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint32_t carry = 0;
+    uint32_t carry = 0, vmax = 0;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
         uint32_t v = 0;
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
                 }
             }
         }
+        vmax = max(vmax, v);
         const uint32_t inc = wave_inclusive_scan(v);
         if (lane == 63) s_wave[w] = inc;
         __syncthreads();
@@ -124,6 +125,14 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         __syncthreads();
     }
     if (tid == 0) { if (tiles) dst[n] = carry; else g.total[0] = carry; }
+    if (tiles) {  // longest tile list: lets the host skip the launches of the rare long-list sort classes
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
+        __syncthreads();
+        if (lane == 0) s_wave[w] = vmax;
+        __syncthreads();
+        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; }
+    }
 }
 
 void launch_scan_small(const ViewK& v, int N, const Geom& g, hipStream_t st) {
@@ -505,13 +514,17 @@ __global__ void __launch_bounds__(256) k_sort_tiles_merge(const Geom g, const Bi
     }
 }
 
-void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, hipStream_t st) {
+// max_len: longest tile list if the host knows it (< 0: unknown, launch every class)
+void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
     auto lds = [](int cap) { return (size_t)(cap + 1024) * 12; };
     hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
+    if (max_len >= 0 && max_len <= 1024) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048>), dim3(tiles), dim3(256), lds(2048), st, g, b, tiles);
+    if (max_len >= 0 && max_len <= 2048) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096>), dim3(tiles), dim3(256), lds(4096), st, g, b, tiles);
+    if (max_len >= 0 && max_len <= 4096) return;
     const int rare_grid = tiles < 128 ? tiles : 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -519,6 +532,7 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, hipStrea
         attr_set = true;
     }
     hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192>), dim3(rare_grid), dim3(256), lds(8192), st, g, b, tiles);
+    if (max_len >= 0 && max_len <= 8192) return;
     hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(rare_grid), dim3(1024), 0, st, g, b, tiles);
 }
 

@@ -47,7 +47,7 @@ struct Geom {
     uint32_t* tile_count;    // [tiles]
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
-    uint32_t* total;         // [1] number of instances
+    uint32_t* total;         // [0] number of instances, [1] longest tile list
     // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
     uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
     uint32_t* segtot;        // [segments][tiles_padded] column totals per segment of kSegRows chunks
