@@ -315,13 +315,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     int radius_in = 0;
     uint32_t first_in = 0, cnt_in = 0;
     uint8_t flags_in = 0;
-    float4 r1_in = make_float4(0.f, 0.f, 0.f, 0.f), q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float opac_in = 0.f;
     float3 p_in = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
     if (valid) {
         radius_in = radii[idx];
         first_in = g.offsets[idx]; cnt_in = g.touched[idx];
         flags_in = g.flags[idx];
-        r1_in = g.rec[4 * (size_t)idx + 1];
+        opac_in = s.opacities[idx];
         p_in = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
         if (!s.cov3D) {
             q_in = reinterpret_cast<const float4*>(s.rotations)[idx];
@@ -363,13 +364,9 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             db += c.x; dd += c.y;
         }
         flags = flags_in;
-        const float4 r1 = r1_in;
-        const float A = r1.x, B = r1.y, C = r1.z, o = r1.w;
+        const float o = opac_in;
         d_opac = S0;
         d_rgb = make_float3(dr, dg, db);
-        // dL/d(NDC mean): (0.5 W, 0.5 H) scaled, the convention scene/gaussian_model.py:427-438 consumes
-        d_m2d.x = -o * (A * Sx + B * Sy) * (0.5f * v.W);
-        d_m2d.y = -o * (B * Sx + C * Sy) * (0.5f * v.H);
         // conic gradients; .y is half of the true dL/dB (off-diagonal counted once, used twice below)
         const float dcon_x = -0.5f * o * Sxx, dcon_y = -0.5f * o * Sxy, dcon_z = -0.5f * o * Syy;
 
@@ -397,6 +394,13 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         const float b = dot3(e.m0, Sm1);
         const float c = dot3(e.m1, Sm1) + kDilation;
         const float denom = a * c - b * b;
+        {   // the conic is recomputed from the inputs (as in the forward) instead of re-reading the 64-byte record
+            const float det_inv = 1.0f / denom;
+            const float A = c * det_inv, B = -b * det_inv, C = a * det_inv;
+            // dL/d(NDC mean): (0.5 W, 0.5 H) scaled, the convention scene/gaussian_model.py:427-438 consumes
+            d_m2d.x = -o * (A * Sx + B * Sy) * (0.5f * v.W);
+            d_m2d.y = -o * (B * Sx + C * Sy) * (0.5f * v.H);
+        }
         const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
         if (denom2inv != 0.f) {
