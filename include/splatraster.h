@@ -131,6 +131,12 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, unsigned char* present, void* hip_stream);
 
+/* mean_dist2[i] = mean squared distance from point i to its 3 nearest other points (exact k-NN).
+ * Replaces [EXT] simple_knn._C.distCUDA2 (reference README.md:29), called once at initialisation by reference
+ * scene/gaussian_model.py:105.  `workspace` holds sr_knn_workspace_bytes(n) bytes of device memory. */
+size_t sr_knn_workspace_bytes(int n_points);
+int sr_knn3_mean_dist2(int n_points, const float* points, float* mean_dist2, void* workspace, void* hip_stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; off by default, adds two event records per launch when on).
  * sr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch counts

@@ -9,7 +9,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libsplatraster.so"
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "knn.hip"]
 HEADERS = ["common.h", "kernels.h", "expand.h", "../../include/splatraster.h"]
 
 

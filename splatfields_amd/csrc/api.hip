@@ -239,6 +239,14 @@ int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const 
     return check_hip(hipGetLastError(), "mark_visible");
 }
 
+size_t sr_knn_workspace_bytes(int n) { return sr::knn_workspace_bytes(n); }
+
+int sr_knn3_mean_dist2(int n, const float* points, float* mean_dist2, void* workspace, void* hip_stream) {
+    if (n < 0 || (n > 0 && (!points || !mean_dist2 || !workspace))) return fail("bad arguments to sr_knn3_mean_dist2");
+    sr::launch_knn3(n, points, mean_dist2, workspace, static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "knn3");
+}
+
 int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 
 int sr_profile_collect(double* ms_sum, long long* launches) {

@@ -34,4 +34,8 @@ void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, con
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* slots, hipStream_t st);
 
+// knn.hip
+size_t knn_workspace_bytes(int n);
+void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream_t st);
+
 }  // namespace sr
