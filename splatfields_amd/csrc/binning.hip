@@ -366,9 +366,10 @@ __device__ __forceinline__ void exchange_select(uint64_t& k, uint32_t& v, uint64
     v = take ? pv : v;
 }
 
+// `tid` is the thread's index inside its 256-thread group (several groups of one workgroup may run the same network
+// side by side on different data; the barriers inside are workgroup-wide, so all groups must call it together).
 template <int N, int E>
-__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint64_t* skey, uint32_t* sval) {
-    const uint32_t tid = threadIdx.x;
+__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint64_t* skey, uint32_t* sval, uint32_t tid) {
 #pragma unroll
     for (int kk = 2; kk <= N; kk <<= 1) {
 #pragma unroll
@@ -421,39 +422,26 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E],
 // thread t holds the entries of rank t*E .. t*E+E-1.
 template <int N, int E>
 __device__ __forceinline__ void load_sort_chunk(const Binning& b, uint32_t first, uint32_t m, uint64_t (&k)[E], uint32_t (&v)[E],
-                                                uint64_t* scratch_key, uint32_t* scratch_val) {
+                                                uint64_t* scratch_key, uint32_t* scratch_val, uint32_t tid) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const uint32_t i = threadIdx.x * E + e;
+        const uint32_t i = tid * E + e;
         const uint4 en = i < m ? b.ent[first + i] : make_uint4(~0u, ~0u, 0u, 0u);
         k[e] = ((uint64_t)en.y << 32) | en.x;
         v[e] = en.z;
     }
-    bitonic_regs<N, E>(k, v, scratch_key, scratch_val);
+    bitonic_regs<N, E>(k, v, scratch_key, scratch_val, tid);
 }
 
 template <int N, int E>
 __device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start, uint32_t n, uint64_t* skey, uint32_t* sval) {
     uint64_t k[E];
     uint32_t v[E];
-    load_sort_chunk<N, E>(b, start, n, k, v, skey, sval);
+    load_sort_chunk<N, E>(b, start, n, k, v, skey, sval, threadIdx.x);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = threadIdx.x * E + e;
         if (i < n) { b.sorted_id[start + i] = v[e]; b.sorted_inst[start + i] = (uint32_t)k[e]; }
-    }
-}
-
-template <int N, int E>
-__device__ __forceinline__ void sort_chunk_to_lds(const Binning& b, uint32_t first, uint32_t m, uint64_t* run_key, uint32_t* run_val,
-                                                  uint64_t* scratch_key, uint32_t* scratch_val) {
-    uint64_t k[E];
-    uint32_t v[E];
-    load_sort_chunk<N, E>(b, first, m, k, v, scratch_key, scratch_val);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const uint32_t i = threadIdx.x * E + e;
-        if (i < m) { run_key[i] = k[e]; run_val[i] = v[e]; }
     }
 }
 
@@ -473,30 +461,38 @@ __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Bin
 
 // lists of (LO, CAP] entries: runs of 1024 sorted by the register network into LDS, then ONE multi-way merge pass --
 // keys are unique, so the final position of an entry is its index in its own run plus, for every other run, the
-// number of smaller keys there (binary search in LDS).  A list of 1100 entries costs a 1024- and a 256-network
-// instead of the 2048-network a power-of-two bitonic sort would need.
-template <int LO, int CAP>
-__global__ void __launch_bounds__(256) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
+// number of smaller keys there (binary search in LDS).  The workgroup has one 256-thread group per run (up to 4),
+// all running the same 1024-network side by side, so a 4096-entry list costs one network latency, not four.
+template <int LO, int CAP, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
+    constexpr int GROUPS = THREADS / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);                 // [CAP]
-    uint64_t* scratch_key = run_key + CAP;                                  // [1024]
-    uint32_t* run_val = reinterpret_cast<uint32_t*>(scratch_key + 1024);    // [CAP]
-    uint32_t* scratch_val = run_val + CAP;                                  // [1024]
+    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);                          // [CAP]
+    uint64_t* scratch_key = run_key + CAP;                                           // [GROUPS][1024]
+    uint32_t* run_val = reinterpret_cast<uint32_t*>(scratch_key + GROUPS * 1024);    // [CAP]
+    uint32_t* scratch_val = run_val + CAP;                                           // [GROUPS][1024]
     if (g.total[0] > b.capacity) return;
+    const uint32_t group = threadIdx.x >> 8, tid = threadIdx.x & 255u;
     for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)LO || n > (uint32_t)CAP) continue;
         const uint32_t n_runs = (n + 1023u) / 1024u;
-        for (uint32_t r = 0; r < n_runs; ++r) {
-            const uint32_t m = min(1024u, n - r * 1024u);
+        for (uint32_t r0 = 0; r0 < n_runs; r0 += GROUPS) {  // uniform trip count: the barriers below are workgroup-wide
+            const uint32_t r = r0 + group;
+            const uint32_t m = r < n_runs ? min(1024u, n - r * 1024u) : 0u;
+            uint64_t k[4];
+            uint32_t v[4];
             __syncthreads();  // scratch reuse
-            if (m <= 256u) sort_chunk_to_lds<256, 1>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
-            else if (m <= 512u) sort_chunk_to_lds<512, 2>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
-            else sort_chunk_to_lds<1024, 4>(b, start + r * 1024u, m, run_key + r * 1024u, run_val + r * 1024u, scratch_key, scratch_val);
+            load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, scratch_key + group * 1024u, scratch_val + group * 1024u, tid);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = tid * 4 + e;
+                if (i < m) { run_key[r * 1024u + i] = k[e]; run_val[r * 1024u + i] = v[e]; }
+            }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
             const uint32_t own = i >> 10;
             const uint64_t key = run_key[i];
             uint32_t rank = i & 1023u;
@@ -518,20 +514,21 @@ __global__ void __launch_bounds__(256) k_sort_tiles_merge(const Geom g, const Bi
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    auto lds = [](int cap) { return (size_t)(cap + 1024) * 12; };
+    auto lds = [](int cap, int threads) { return (size_t)(cap + threads / 256 * 1024) * 12; };
     hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
     if (max_len >= 0 && max_len <= 1024) return;
-    hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048>), dim3(tiles), dim3(256), lds(2048), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 2048) return;
-    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096>), dim3(tiles), dim3(256), lds(4096), st, g, b, tiles);
-    if (max_len >= 0 && max_len <= 4096) return;
-    const int rare_grid = tiles < 128 ? tiles : 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4096, 1024));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192>), dim3(rare_grid), dim3(256), lds(8192), st, g, b, tiles);
+    const int rare_grid = tiles < 128 ? tiles : 128;
+    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(max_len >= 0 ? rare_grid : tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
+    if (max_len >= 0 && max_len <= 4096) return;
+    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(rare_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 8192) return;
     hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(rare_grid), dim3(1024), 0, st, g, b, tiles);
 }
