@@ -39,6 +39,9 @@ def parse():
     p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--cpu-baseline", choices=["auto", "none"], default="auto")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded baseline sample")
+    p.add_argument("--dp-mode", choices=["gather", "allreduce"], default="gather",
+                   help="N>1, SH path: 'gather' exchanges 12 B/splat colour gradients and rebuilds the SH gradient locally "
+                        "(splatfields_amd.view_parallel.sh_gather_step); 'allreduce' sum-all-reduces all five gradient tensors")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing the control flow)")
     p.add_argument("--single-device", action="store_true", help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
     return p.parse_args()
@@ -90,7 +93,7 @@ def main():
     from splatfields_amd import _lib, rasterizer as rz
     from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-    from splatfields_amd.view_parallel import allreduce_gradients
+    from splatfields_amd.view_parallel import allreduce_gradients, sh_gather_step
     import math
 
     lib = _lib.load()
@@ -105,7 +108,25 @@ def main():
     cams = [make_camera(k, W, H, device=dev) for k in range(8)]
     stats = {"R": 0.0, "vis": 0.0, "n": 0}
 
+    gather = world > 1 and use_sh and args.dp_mode == "gather"
+
+    def one_step_gather(step_idx: int, record: bool):
+        step_cams = [cams[(step_idx * world + r) % len(cams)] for r in range(world)]
+        seen = {}
+
+        def bwd(vi, color, depth, alpha):
+            seen["radii_vis"] = None
+            torch.autograd.backward((color, depth, alpha), (gi / world, gd / world, ga / world))
+
+        sh_gather_step(params, step_cams, bg, args.sh_degree, bwd, rank=rank, world=world)
+        if record:
+            stats["R"] += rz.LAST_INSTANCES
+            stats["vis"] += float(N)
+            stats["n"] += 1
+
     def one_step(step_idx: int, record: bool = False):
+        if gather:
+            return one_step_gather(step_idx, record)
         cam = cams[(step_idx * world + rank) % len(cams)]
         rs = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
@@ -181,7 +202,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
                                f"1 view per GPU per step, colour+depth+alpha outputs, fwd+bwd"
-                               + (", RCCL sum all-reduce of per-splat gradients" if world > 1 else ""),
+                               + ((", RCCL all-gather of colour gradients + all-reduce of the other per-splat gradients"
+                                   if gather else ", RCCL sum all-reduce of per-splat gradients") if world > 1 else ""),
                    "splats": N, "width": W, "height": H, "views_per_step": world,
                    "visible_splats": vis, "tile_instances": R},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -82,7 +82,9 @@ typedef struct SrGrads {
     float* dL_drotations; /* [N,4] or NULL with cov3D_precomp */
     float* dL_dcov3D;     /* [N,6] or NULL unless cov3D_precomp */
     float* dL_dshs;       /* [N,K,3] or NULL */
-    float* dL_dcolors;    /* [N,3] or NULL */
+    float* dL_dcolors;    /* [N,3] or NULL.  With SH input, dL_dshs == NULL and dL_dcolors != NULL selects the colour-gradient
+                           * mode: the clamp-masked dL/dcolour is written instead of dL/dsh (view-parallel exchange, sr_sh_backward);
+                           * the gradient through the view direction is still added to dL_dmeans3D. */
 } SrGrads;
 
 int sr_version(void);
@@ -130,6 +132,20 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
 /* present[i] = 1 iff splat i passes the near-plane test (view z > 0.2). */
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, unsigned char* present, void* hip_stream);
+
+/* SH colour evaluation as a stand-alone stage (the SH part of the forward preprocess; reference utils/sh_utils.py:57-112,
+ * extract_geo.py:40-44): colors[N,3] = max(sum_k basis_k(dir) shs[k] + 0.5, 0), clamped[N] bit c set where channel c was
+ * clamped.  Feeding `colors` to sr_forward as colors_precomp gives the same image as passing `shs`. */
+int sr_sh_forward(int n_splats, int sh_coeffs, int sh_degree, const float* means3D, const float* shs, const float* campos,
+                  float* colors, unsigned char* clamped, void* hip_stream);
+
+/* Backward of sr_sh_forward for n_views cameras at once (view-parallel training).
+ * campos [n_views,3]; dL_dcolors [n_views,N,3], zero where the colour was clamped in that view.
+ * dL_dshs [N,K,3] (may be NULL) = scale * sum_v basis(dir_v) (x) dL_dcolors[v];
+ * dL_dmeans3D [N,3] (may be NULL) = or += scale * the gradient through the view direction. */
+int sr_sh_backward(int n_splats, int sh_coeffs, int sh_degree, int n_views, const float* means3D, const float* shs,
+                   const float* campos, const float* dL_dcolors, float scale, float* dL_dshs, float* dL_dmeans3D,
+                   int accumulate_means, void* hip_stream);
 
 /* mean_dist2[i] = mean squared distance from point i to its 3 nearest other points (exact k-NN).
  * Replaces [EXT] simple_knn._C.distCUDA2 (reference README.md:29), called once at initialisation by reference

@@ -9,8 +9,8 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libsplatraster.so"
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "knn.hip"]
-HEADERS = ["common.h", "kernels.h", "expand.h", "../../include/splatraster.h"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "knn.hip", "sh.hip"]
+HEADERS = ["common.h", "kernels.h", "expand.h", "sh_stage.h", "../../include/splatraster.h"]
 
 
 def _hipcc() -> str:

@@ -208,7 +208,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     SR_TRY(validate(view, splats));
     if (!geom || !binning || !image || !dL_dcolor || !scratch || !grads) return fail("null buffer");
     if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
-    if (splats->count > 0 && splats->shs && !grads->dL_dshs) return fail("dL_dshs missing");
+    if (splats->count > 0 && splats->shs && !grads->dL_dshs && !grads->dL_dcolors) return fail("dL_dshs (or dL_dcolors for the colour-gradient mode) missing");
     if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
     if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
     if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
@@ -226,7 +226,8 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
     gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
     gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
-    gr.shs = s.shs ? grads->dL_dshs : nullptr; gr.colors = s.colors ? grads->dL_dcolors : nullptr;
+    gr.shs = s.shs ? grads->dL_dshs : nullptr;
+    gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
     { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, gr, st); }
     SR_TRY(after_launch(view, st, "preprocess_backward"));
     return 0;
@@ -237,6 +238,23 @@ int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const 
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     sr::launch_mark_visible(n, means3D, viewmatrix, present, st);
     return check_hip(hipGetLastError(), "mark_visible");
+}
+
+int sr_sh_forward(int n, int sh_coeffs, int sh_degree, const float* means3D, const float* shs, const float* campos,
+                  float* colors, unsigned char* clamped, void* hip_stream) {
+    if (n < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail("bad arguments to sr_sh_forward");
+    if (n > 0 && (!means3D || !shs || !campos || !colors || !clamped)) return fail("null pointer in sr_sh_forward");
+    sr::launch_sh_forward(n, sh_coeffs, sh_degree, means3D, shs, campos, colors, clamped, static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "sh_forward");
+}
+
+int sr_sh_backward(int n, int sh_coeffs, int sh_degree, int n_views, const float* means3D, const float* shs, const float* campos,
+                   const float* dL_dcolors, float scale, float* dL_dshs, float* dL_dmeans3D, int accumulate_means, void* hip_stream) {
+    if (n < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail("bad arguments to sr_sh_backward");
+    if (n > 0 && n_views > 0 && (!means3D || !shs || !campos || !dL_dcolors)) return fail("null pointer in sr_sh_backward");
+    sr::launch_sh_backward(n, sh_coeffs, sh_degree, n_views, means3D, shs, campos, dL_dcolors, scale, dL_dshs, dL_dmeans3D, accumulate_means,
+                           static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "sh_backward");
 }
 
 size_t sr_knn_workspace_bytes(int n) { return sr::knn_workspace_bytes(n); }

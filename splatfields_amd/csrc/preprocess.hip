@@ -8,6 +8,7 @@
 // One thread per splat, 256-thread workgroups; all traffic is per-splat streaming (HBM-bound).
 #include "kernels.h"
 #include "expand.h"
+#include "sh_stage.h"
 
 namespace sr {
 
@@ -89,40 +90,6 @@ __device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
 // ------------------------------------------------------------------------------------------
 // Forward preprocess
 // ------------------------------------------------------------------------------------------
-// SH staging: with K = 16 coefficients a splat's SH block is 192 contiguous bytes, so the 256 splats of a
-// workgroup own one contiguous 48 KiB span.  It is moved with fully coalesced 16-byte loads/stores through LDS
-// (rows padded to 13 float4 = 208 B) instead of 48 strided 4-byte accesses per lane.
-constexpr int kShRowF4 = 13;
-
-// 256 splats x 12 float4: every thread moves 12 float4, all 12 global loads issued before the first LDS write
-// (the naive loop compiled to load -> s_waitcnt vmcnt(0) -> ds_write per iteration: one load in flight per lane).
-__device__ __forceinline__ void stage_sh_in(float4* s_sh, const float* shs, size_t first_splat, int n_here) {
-    const float4* src = reinterpret_cast<const float4*>(shs + first_splat * 48);
-    const int total = n_here * 12;
-    float4 tmp[12];
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int i = it * kBlock + (int)threadIdx.x;
-        tmp[it] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int i = it * kBlock + (int)threadIdx.x;
-        const int sp = i / 12;
-        if (i < total) s_sh[sp * kShRowF4 + (i - sp * 12)] = tmp[it];
-    }
-}
-__device__ __forceinline__ void stage_sh_out(const float4* s_sh, float* dst_base, size_t first_splat, int n_here) {
-    float4* dst = reinterpret_cast<float4*>(dst_base + first_splat * 48);
-    const int total = n_here * 12;
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int i = it * kBlock + (int)threadIdx.x;
-        const int sp = i / 12;
-        if (i < total) dst[i] = s_sh[sp * kShRowF4 + (i - sp * 12)];
-    }
-}
-
 template <bool STAGE_SH, bool COUNT_ATOMIC>
 __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
     __shared__ uint32_t s_off[COUNT_ATOMIC ? kBlock + 1 : 1];
@@ -303,7 +270,10 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 // ------------------------------------------------------------------------------------------
 // Backward preprocess
 // ------------------------------------------------------------------------------------------
-template <bool STAGE_SH>
+// SH_TO_COLORS: the splats carry SH, but instead of dL/dsh [N,K,3] the kernel writes the (clamp-masked) colour gradient
+// dL/dcolour [N,3] -- the view-parallel step all-gathers those 12 bytes and rebuilds the SH gradient of all views
+// locally (sh.hip); the gradient through the view direction still goes into dL/dmeans3D here.
+template <bool STAGE_SH, bool SH_TO_COLORS>
 __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
                                                                 const int* __restrict__ radii,
                                                                 const float* __restrict__ slots, const GradsK gr) {
@@ -475,7 +445,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }
 
     // ---- colour: SH coefficients and view direction, or precomputed colours ----
-    if (gr.shs) {
+    if (gr.shs || SH_TO_COLORS) {
         // staged: this thread's LDS row first supplies its SH coefficients, then receives its gradients
         float* out = STAGE_SH ? reinterpret_cast<float*>(&s_sh[threadIdx.x * kShRowF4]) : gr.shs + (size_t)idx * K * 3;
         int nb = 0;
@@ -497,8 +467,9 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             for (int k = 0; k < nb; ++k) {
                 const float c0 = sh[3 * k], c1 = sh[3 * k + 1], c2 = sh[3 * k + 2];  // read before the row is overwritten
                 gk[k] = c0 * dc.x + c1 * dc.y + c2 * dc.z;
-                out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z;
+                if (!SH_TO_COLORS) { out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z; }
             }
+            if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
             float3 dd_ = make_float3(0.f, 0.f, 0.f);  // dL/d(unit direction)
             if (v.sh_degree > 0) {
                 const float x = d.x, y = d.y, z = d.z;
@@ -527,7 +498,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                 d_mean.z += (dd_.z - d.z * proj) * inv_len;
             }
         }
-        for (int k = nb; k < K; ++k) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
     }
     if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
 
@@ -538,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
     }  // valid
-    if constexpr (STAGE_SH) {
+    if constexpr (STAGE_SH && !SH_TO_COLORS) {
         __syncthreads();
         const size_t first = (size_t)blockIdx.x * kBlock;
         stage_sh_out(s_sh, gr.shs, first, min(kBlock, s.N - (int)first));
@@ -549,8 +520,12 @@ void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g,
                                 const float* slots, const GradsK& gr, hipStream_t st) {
     const int nb = (s.N + kBlock - 1) / kBlock;
     if (nb <= 0) return;
-    if (gr.shs && v.sh_coeffs == 16) hipLaunchKernelGGL(k_preprocess_backward<true>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
-    else hipLaunchKernelGGL(k_preprocess_backward<false>, dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    const bool to_colors = s.shs && !gr.shs && gr.colors;
+    const bool stage = s.shs && v.sh_coeffs == 16 && (gr.shs || (to_colors && v.sh_degree >= 2));
+    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
 }
 
 }  // namespace sr

@@ -92,7 +92,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, color_grad_sink=None):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -120,6 +120,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         radii = torch.zeros(n, dtype=torch.int32, device=dev)
         ctx.raster_settings = raster_settings
+        ctx.color_grad_sink = color_grad_sink
         ctx.sh_coeffs = sh_coeffs
         ctx.n = n
         ctx.opac_shape = tuple(opacities.shape)
@@ -167,7 +168,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         n = ctx.n
         if n == 0:
-            return (None,) * 9
+            return (None,) * 10
         lib = _lib.load()
         means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image = ctx.saved_tensors
         dev = means3D.device
@@ -183,8 +184,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_sc = new(n, 3) if sc is not None else None
         d_rot = new(n, 4) if rot is not None else None
         d_cov = new(n, 6) if cov is not None else None
-        d_sh = new(*sh.shape) if sh is not None else None
-        d_col = new(n, 3) if col is not None else None
+        sink = ctx.color_grad_sink if sh is not None else None
+        d_sh = new(*sh.shape) if (sh is not None and sink is None) else None
+        d_col = new(n, 3) if (col is not None or sink is not None) else None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col)
@@ -195,16 +197,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
                                        _ptr(scratch), C.byref(grads), stream))
         # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings
-        return d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov, None
+        if sink is not None:
+            sink.append(d_col)  # clamp-masked dL/dcolour of this view; dL/dsh is rebuilt from all views by the caller
+            d_col = None
+        return d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, color_grad_sink=None):
     """Returns (color, radii, depth, alpha).  ``alpha`` (= 1 - final transmittance) is the fused equivalent of
     the reference's second rasterization with white colours on a black background
     (gaussian_renderer/__init__.py:104-115)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, color_grad_sink)
 
 
 class GaussianRasterizer(nn.Module):
@@ -235,11 +240,15 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
     def forward_ex(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                   cov3D_precomp=None):
-        """Same as ``forward`` plus the fused alpha image: (color, radii, depth, alpha)."""
+                   cov3D_precomp=None, color_grad_sink=None):
+        """Same as ``forward`` plus the fused alpha image: (color, radii, depth, alpha).
+
+        ``color_grad_sink`` (a list, SH path only): the backward appends the clamp-masked dL/dcolour [N,3] of this view to
+        it and returns no gradient for ``shs`` -- used by the view-parallel step, which exchanges colour gradients and
+        rebuilds the SH gradient of all views locally (splatfields_amd/view_parallel.py)."""
         self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings)
+                                   self.raster_settings, color_grad_sink)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):

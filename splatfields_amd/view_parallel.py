@@ -45,6 +45,72 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None) 
             g.mul_(scale)
 
 
+def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
+                   rank: int = None, world: int = None, group=None) -> None:
+    """View-parallel step for the SH colour path with the low-rank gradient exchange.
+
+    ``params``: dict of leaf tensors ``means3D, scales, rotations, opacities, shs`` (replicated on every rank).
+    ``cams``: the V cameras of this step (same list on every rank; rank r renders cams[r::world]).
+    ``backward_fn(view_index, color, depth, alpha)`` must back-propagate the loss of that view *already divided by V*
+    (e.g. ``(loss / V).backward()`` or ``torch.autograd.backward(outputs, upstream_grads / V)``).
+
+    Afterwards every rank holds in ``p.grad`` the gradient of the mean loss over all V views -- the same result as
+    all-reducing all five gradient tensors, but the 192 B/splat SH gradient never crosses xGMI: for one view it is
+    basis(view direction) (x) dL/dcolour, so ranks all-gather the 12 B/splat colour gradients of all views and rebuild
+    the sum locally (sr_sh_backward).  Wire traffic per rank drops from ~413 to ~161 bytes per splat."""
+    import math
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from . import sh as shmod
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    V = len(cams)
+    if V % world != 0:
+        raise ValueError("the number of views must be a multiple of the number of ranks")
+    names = ["means3D", "scales", "rotations", "opacities"]
+    for p in params.values():
+        p.grad = None
+    means3D, shs = params["means3D"], params["shs"]
+    dev = means3D.device
+    n = means3D.shape[0]
+    mine = list(range(rank, V, world))
+    dcol_views = []
+    for slot, vi in enumerate(mine):
+        cam = cams[vi]
+        rs = GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+        sink = []
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
+            shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink)
+        # the rasterizer's backward accumulates the 4 small gradients (incl. the view-direction term in means3D) and hands
+        # over the clamp-masked colour gradient instead of writing 192 B/splat of SH gradient
+        backward_fn(vi, color, depth, alpha)
+        dcol_views.append(sink.pop())
+    for k in names:
+        if params[k].grad is None:
+            params[k].grad = torch.zeros_like(params[k])
+    dcol_local = dcol_views[0][None] if len(dcol_views) == 1 else torch.stack(dcol_views)
+    campos_all = torch.stack([c.camera_center.to(device=dev, dtype=torch.float32).reshape(3) for c in cams])
+    if world > 1:
+        gathered = torch.empty(world, len(mine), n, 3, dtype=torch.float32, device=dev)
+        works = [dist.all_gather_into_tensor(gathered.view(-1), dcol_local.view(-1), group=group, async_op=True)]
+        works += [dist.all_reduce(params[k].grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                  for k in sorted(names, key=lambda q: -params[q].numel())]
+        for w in works:
+            w.wait()
+        # gathered[r, slot] is view r + slot*world
+        order = [r + sl * world for r in range(world) for sl in range(len(mine))]
+        dcol_all = gathered.reshape(world * len(mine), n, 3)
+        campos_used = campos_all if order == list(range(V)) else campos_all[torch.tensor(order, device=dev)]
+    else:
+        dcol_all, campos_used = dcol_local, campos_all
+    params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
+
+
 def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss: Callable, *, rank: int = None,
                        world: int = None, group=None) -> torch.Tensor:
     """One data-parallel step.  ``render_loss(view) -> scalar loss`` renders one view with the shared

@@ -1,0 +1,137 @@
+"""Stand-alone SH stage and the low-rank gradient exchange of the view-parallel step."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import torch_oracle as O
+from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+
+pytestmark = pytest.mark.gpu
+N, W, H, V, DEG = 6000, 160, 128, 4, 3
+NAMES = ["means3D", "scales", "rotations", "opacities", "shs"]
+
+
+def test_sh_to_rgb_matches_oracle(hip_device):
+    from splatfields_amd.sh import sh_to_rgb
+    sp = make_splats(5000, seed=3)
+    sp["shs"] = sp["shs"] * 3.0  # make the clamp at 0 bite
+    cam = make_camera(2, 64, 64)
+    for deg in range(4):
+        m = sp["means3D"].to(hip_device).requires_grad_(True)
+        s = sp["shs"].to(hip_device).requires_grad_(True)
+        col = sh_to_rgb(m, s, cam.camera_center.to(hip_device), deg)
+        g = torch.randn(5000, 3, generator=torch.Generator().manual_seed(deg))
+        (col * g.to(hip_device)).sum().backward()
+        m64 = sp["means3D"].double().requires_grad_(True)
+        s64 = sp["shs"].double().requires_grad_(True)
+        ref = O.sh_to_rgb(deg, s64, m64, cam.camera_center.double())
+        (ref * g.double()).sum().backward()
+        assert (ref == 0).any()
+        assert torch.allclose(col.detach().cpu().double(), ref.detach(), atol=2e-6)
+        assert torch.allclose(s.grad.cpu().double(), s64.grad, atol=1e-5 * s64.grad.abs().max().item())
+        mref = m64.grad if m64.grad is not None else torch.zeros_like(m64)  # degree 0 does not depend on the direction
+        assert torch.allclose(m.grad.cpu().double(), mref, atol=1e-4 * max(mref.abs().max().item(), 1e-12))
+
+
+def _rs(cam, dev, deg=DEG):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
+                                         torch.ones(3, device=dev), 1.0, cam.world_view_transform, cam.full_proj_transform, deg,
+                                         cam.camera_center, False, False)
+
+
+def test_shs_path_equals_precomputed_colours_of_sh_stage(hip_device):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from splatfields_amd.sh import sh_to_rgb
+    dev = hip_device
+    sp = make_splats(N, seed=5, device=dev)
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    cam = make_camera(1, W, H, device=dev)
+    res = []
+    for split in (False, True):
+        p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+        kw = dict(means3D=p["means3D"], means2D=torch.zeros_like(p["means3D"]), opacities=p["opacities"], scales=p["scales"],
+                  rotations=p["rotations"])
+        if split:
+            kw["colors_precomp"] = sh_to_rgb(p["means3D"], p["shs"], cam.camera_center, DEG)
+        else:
+            kw["shs"] = p["shs"]
+        c, r, d, a = GaussianRasterizer(_rs(cam, dev)).forward_ex(**kw)
+        torch.autograd.backward((c, d, a), (gi, gd, ga))
+        res.append((c.detach(), {k: v.grad.clone() for k, v in p.items()}))
+    assert torch.allclose(res[0][0], res[1][0], atol=1e-6)
+    for k in NAMES:
+        scale = res[0][1][k].abs().max().item()
+        assert torch.allclose(res[0][1][k], res[1][1][k], atol=2e-5 * scale), k
+
+
+def _reference_grads(dev):
+    """plain path: every view through the SH rasterizer, mean of the views, one backward (reference train.py:169-252)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sp = make_splats(N, seed=7, device=dev)
+    p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    for v in range(V):
+        cam = make_camera(v, W, H, device=dev)
+        c, r, d, a = GaussianRasterizer(_rs(cam, dev)).forward_ex(means3D=p["means3D"], means2D=torch.zeros_like(p["means3D"]),
+                                                                  opacities=p["opacities"], shs=p["shs"], scales=p["scales"],
+                                                                  rotations=p["rotations"])
+        torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
+    return {k: v.grad.detach().cpu() for k, v in p.items()}
+
+
+def _gather_grads(dev, rank, world):
+    from splatfields_amd.view_parallel import sh_gather_step
+    sp = make_splats(N, seed=7, device=dev)
+    p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    cams = [make_camera(v, W, H, device=dev) for v in range(V)]
+
+    def bwd(vi, c, d, a):
+        torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
+
+    sh_gather_step(p, cams, torch.ones(3, device=dev), DEG, bwd, rank=rank, world=world)
+    torch.cuda.synchronize()
+    return {k: v.grad.detach().cpu() for k, v in p.items()}
+
+
+def _close(a, b):
+    for k in NAMES:
+        scale = b[k].abs().max().item()
+        assert torch.allclose(a[k], b[k], atol=5e-5 * scale), (k, (a[k] - b[k]).abs().max().item() / scale)
+
+
+def test_gather_step_single_rank_equals_plain_multiview(hip_device):
+    _close(_gather_grads(hip_device, 0, 1), _reference_grads(hip_device))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")  # both ranks share the single GPU of the test box; gloo moves the tensors
+    torch.cuda.set_device(dev)
+    g = _gather_grads(dev, rank, world)
+    q.put((rank, {k: v.numpy().copy() for k, v in g.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_step_two_ranks_equals_plain_multiview(hip_device):
+    ref = _reference_grads(hip_device)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, g in outs:
+        _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
