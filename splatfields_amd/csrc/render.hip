@@ -18,7 +18,7 @@
 namespace sr {
 
 constexpr int kFwdBatch = 256;
-constexpr int kBwdBatch = 128;
+constexpr int kBwdBatch = 128;  // 64 and 256 measured slower (0.541 / 0.680 vs 0.528 ms)
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -26,6 +26,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Tile order: workgroup b renders tile b.  Consecutive workgroups land on different XCDs (b % 8), which interleaves
+// heavy (image centre) and light tiles across the 8 XCDs.  Dealing each XCD a contiguous band of tiles for L2 locality
+// was measured and is WORSE (forward 0.163 -> 0.219 ms, backward 0.528 -> 0.639 ms): the kernels are VALU-bound, so the
+// XCD load imbalance costs more than the shared-record L2 hits save.
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
 // x, y hold two different quantities per lane.  Returns r with r[l] = x[l] + x[l+32] for l < 32 and
