@@ -178,9 +178,6 @@ __device__ __forceinline__ float dpp_add(float v) {
 
 // Sum over the 64 lanes of a wavefront; the total is valid in lane 63 only.
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#ifdef SR_EXP_NO_REDUCE
-    return v;
-#endif
     v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
     v = dpp_add<0x124>(v);       // row_ror:4

@@ -88,15 +88,8 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             for (int c = 0; c < cnt; c += kWave) {
                 const int el = c + lane;
                 const int ec = el < cnt ? el : cnt - 1;
-#ifdef SR_EXP_FWD_NOCULL
-                const bool ok = false;
-#else
                 const bool ok = el < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
-#endif
                 uint64_t m = __ballot(ok);
-#ifdef SR_EXP_FWD_NOLOOP
-                m = 0;
-#endif
                 const uint32_t pos0 = (base - start) + (uint32_t)c + 1u;
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
