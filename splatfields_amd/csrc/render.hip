@@ -132,6 +132,9 @@ void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, cons
 // ------------------------------------------------------------------------------------------
 // Backward
 // ------------------------------------------------------------------------------------------
+// HAS_D / HAS_A: the caller supplied dL/ddepth / dL/dalpha.  SplatFields' default losses leave the depth gradient
+// empty (reference arguments/__init__.py:166,168), so the depth channel's replay and its wave reduction are compiled out.
+template <bool HAS_D, bool HAS_A>
 __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const Geom g, const Binning b, const Image im,
                                                             const float* __restrict__ dL_dcolor,
                                                             const float* __restrict__ dL_ddepth,
@@ -162,8 +165,8 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         my_last = (int)im.n_contrib[pix];
         T_final = im.final_T[pix];
         gR = dL_dcolor[pix]; gG = dL_dcolor[hw + pix]; gB = dL_dcolor[2 * hw + pix];
-        if (dL_ddepth) gD = dL_ddepth[pix];
-        if (dL_dalpha) gA = dL_dalpha[pix];
+        if (HAS_D) gD = dL_ddepth[pix];
+        if (HAS_A) gA = dL_dalpha[pix];
     }
     const float bg_dot = v.bg[0] * gR + v.bg[1] * gG + v.bg[2] * gB;
 
@@ -236,9 +239,9 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                             acR = last_alpha * lR + keep * acR; lR = r2.x;
                             acG = last_alpha * lG + keep * acG; lG = r2.y;
                             acB = last_alpha * lB + keep * acB; lB = r2.z;
-                            acD = last_alpha * lD + keep * acD; lD = r0.w;
-                            acA = last_alpha + keep * acA;  // the alpha channel's "colour" is 1 for every splat
-                            float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB + (r0.w - acD) * gD + (1.0f - acA) * gA;
+                            float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB;
+                            if (HAS_D) { acD = last_alpha * lD + keep * acD; lD = r0.w; dLa += (r0.w - acD) * gD; }
+                            if (HAS_A) { acA = last_alpha + keep * acA; dLa += (1.0f - acA) * gA; }  // the alpha channel's "colour" is 1
                             dLa *= T;
                             last_alpha = alpha;
                             dLa += (-T_final * inv_keep) * bg_dot;
@@ -246,13 +249,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         }
                         const float sxv = g1 * dx, syv = g1 * dy;
                         pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
-                        pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = wgt * gD;
+                        pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = HAS_D ? wgt * gD : 0.f;
                         any = any || contrib;
                     }
                     if (__ballot(any) == 0ull) continue;
                     float red[10];
+                    red[9] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) {
+                    for (int k = 0; k < (HAS_D ? 10 : 9); ++k) {
                         const float z01 = swap32_add(pv[0][k], pv[1][k]);   // lanes 0-31: entry 0, lanes 32-63: entry 1
                         const float z23 = swap32_add(pv[2][k], pv[3][k]);   // lanes 0-31: entry 2, lanes 32-63: entry 3
                         float w = swap16_add(z01, z23);                     // rows: 0 -> entry 0, 1 -> entry 2, 2 -> entry 1, 3 -> entry 3
@@ -289,7 +293,12 @@ void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, con
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* slots, hipStream_t st) {
     const int tiles = v.gx * v.gy;
-    if (tiles > 0) hipLaunchKernelGGL(k_render_backward, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    if (tiles <= 0) return;
+    const bool d = dL_ddepth != nullptr, a = dL_dalpha != nullptr;
+    if (d && a) hipLaunchKernelGGL((k_render_backward<true, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else if (d) hipLaunchKernelGGL((k_render_backward<true, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else if (a) hipLaunchKernelGGL((k_render_backward<false, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else hipLaunchKernelGGL((k_render_backward<false, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
 }
 
 }  // namespace sr

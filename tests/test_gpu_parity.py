@@ -206,3 +206,14 @@ def test_large_image_global_atomic_fallback(hip_device):
         assert (out[k].double() - cout[k].double()).abs().max().item() <= 2e-2 * max(1.0, cout[k].abs().max().item()), k
     for k in cg:
         assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
+
+
+@pytest.mark.parametrize("with_depth,with_alpha", [(False, False), (True, False), (False, True)])
+def test_backward_variants_without_depth_or_alpha_gradients(hip_device, with_depth, with_alpha):
+    """SplatFields' default losses use colour (+ alpha mask) only; the backward kernel has compiled-out variants."""
+    sp, cam, st, grads = make_scene(5000, 144, 112, view=4)
+    out, g = run_hip(sp, st, grads, hip_device, with_depth=with_depth, with_alpha=with_alpha)
+    ref, gr = O.fwd_bwd(sp, st, grads[0], grads[1] if with_depth else None, grads[2] if with_alpha else None,
+                        use_sh=True, dtype=torch.float64)
+    for k in g:
+        assert grad_error(g[k], gr[k]) <= GRAD_TOL64, (k, grad_error(g[k], gr[k]))
