@@ -481,14 +481,27 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, cons
         for (uint32_t r0 = 0; r0 < n_runs; r0 += GROUPS) {  // uniform trip count: the barriers below are workgroup-wide
             const uint32_t r = r0 + group;
             const uint32_t m = r < n_runs ? min(1024u, n - r * 1024u) : 0u;
-            uint64_t k[4];
-            uint32_t v[4];
             __syncthreads();  // scratch reuse
-            load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, scratch_key + group * 1024u, scratch_val + group * 1024u, tid);
+            // Every network size has exactly 3 cross-wavefront (LDS) stages = 6 workgroup barriers, so groups may run
+            // differently sized networks side by side: a short last run does not pay for a 1024-network.
+            uint64_t* sk = scratch_key + group * 1024u;
+            uint32_t* sv = scratch_val + group * 1024u;
+            uint64_t* rk = run_key + r * 1024u;
+            uint32_t* rv = run_val + r * 1024u;
+            if (m <= 256u) {
+                uint64_t k[1]; uint32_t v[1];
+                load_sort_chunk<256, 1>(b, start + r * 1024u, m, k, v, sk, sv, tid);
+                if (tid < m) { rk[tid] = k[0]; rv[tid] = v[0]; }
+            } else if (m <= 512u) {
+                uint64_t k[2]; uint32_t v[2];
+                load_sort_chunk<512, 2>(b, start + r * 1024u, m, k, v, sk, sv, tid);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t i = tid * 4 + e;
-                if (i < m) { run_key[r * 1024u + i] = k[e]; run_val[r * 1024u + i] = v[e]; }
+                for (int e = 0; e < 2; ++e) { const uint32_t i = tid * 2 + e; if (i < m) { rk[i] = k[e]; rv[i] = v[e]; } }
+            } else {
+                uint64_t k[4]; uint32_t v[4];
+                load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, sk, sv, tid);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const uint32_t i = tid * 4 + e; if (i < m) { rk[i] = k[e]; rv[i] = v[e]; } }
             }
         }
         __syncthreads();

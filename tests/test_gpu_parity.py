@@ -217,3 +217,9 @@ def test_backward_variants_without_depth_or_alpha_gradients(hip_device, with_dep
                         use_sh=True, dtype=torch.float64)
     for k in g:
         assert grad_error(g[k], gr[k]) <= GRAD_TOL64, (k, grad_error(g[k], gr[k]))
+
+
+@pytest.mark.parametrize("w,h", [(7, 5), (16, 16), (17, 33)])
+def test_images_smaller_than_or_barely_above_one_tile(hip_device, w, h):
+    sp, cam, st, grads = make_scene(400, w, h, mean_scale=0.2, view=6)
+    check_against_oracles(sp, st, grads, hip_device, max_fragile=0.2)
