@@ -35,8 +35,8 @@ constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampT
 // ---- carved views of the caller-owned opaque buffers ---------------------------------------
 struct Geom {
     // [N][4] one 64-byte, 64-byte-aligned record per splat, so a gather touches exactly one cache line:
-    //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) [support: d^T Q d <= tau; < 0: never visible], view depth)
-    //   q1 = (conic A, B, C, opacity)      q2 = (r, g, b, unused)      q3 = unused
+    //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) * log2(e) [support: d^T Q' d <= tau; < 0: never visible], view depth)
+    //   q1 = (conic A, B, C scaled by log2(e) = Q', opacity)      q2 = (r, g, b, unused)      q3 = unused
     float4* rec;
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
     uint32_t* touched;   // [N] instances emitted by this splat
@@ -219,9 +219,11 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
 
 // The alpha of one (pixel, splat) pair -- shared by forward and backward so both make the same
 // skip decisions.  Returns false when the pair is skipped (power > 0 or alpha < 1/255).
+// The conic in the per-splat record is pre-multiplied by log2(e) (and so is tau), so exp(power) is one v_exp_f32.
+constexpr float kLog2e = 1.4426950408889634f;
 __device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_o, float& G, float& alpha) {
-    const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;
-    G = __expf(power);
+    const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;  // = ln-power * log2(e)
+    G = __builtin_amdgcn_exp2f(power);
     alpha = fminf(kAlphaMax, con_o.w * G);
     return (power <= 0.0f) && (alpha >= kAlphaMin);
 }
@@ -247,7 +249,7 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
     fmin_ = fminf(fmin_, edge_min(A, B2, C, inv_c, x1, y0, y1));
     fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y0, x0, x1));
     fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y1, x0, x1));
-    return fmin_ <= tau * 1.002f + 0.02f;
+    return fmin_ <= tau * 1.002f + 0.03f;
 }
 
 #endif  // __HIPCC__

@@ -210,8 +210,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         if (rgb.z < 0.f) { flags |= kFlagClampB; rgb.z = 0.f; }
                     }
                     float4* rec = g.rec + 4 * (size_t)idx;
-                    rec[0] = make_float4(px, py, tau > 0.0f ? tau : -1.0f, pv.z);
-                    rec[1] = make_float4(cA, cB, cC, opac);
+                    rec[0] = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
+                    rec[1] = make_float4(cA * kLog2e, cB * kLog2e, cC * kLog2e, opac);
                     rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
                 }
             }

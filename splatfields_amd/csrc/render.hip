@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     const bool hit = pair_alpha(r0.x - pxf, r0.y - pyf, r1, G, alpha) && !done;
                     const float test_T = T * (1.0f - alpha);
                     const bool stop = hit && (test_T < kTStop);
-                    const bool blend = hit && !stop;
+                    const bool blend = hit != stop;  // stop implies hit: one compare, a mask xor
                     done = done || stop;
                     const float w = blend ? alpha * T : 0.0f;
                     Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r0.w, w, D);
