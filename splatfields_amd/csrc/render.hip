@@ -187,7 +187,6 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
     float T = T_final;
     float acR = 0.f, acG = 0.f, acB = 0.f, acD = 0.f, acA = 0.f;       // colour accumulated behind
-    float last_alpha = 0.f, lR = 0.f, lG = 0.f, lB = 0.f, lD = 0.f;
 
     for (int top = bmax; top > 0; top -= kBwdBatch) {
         const int cnt = min(kBwdBatch, top);
@@ -232,19 +231,22 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
                         float g1 = 0.f, wgt = 0.f;
                         if (contrib) {
-                            const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
+                            const float keep = 1.0f - alpha;
+                            const float inv_keep = __builtin_amdgcn_rcpf(keep);  // v_rcp_f32, 1 ulp
                             T = T * inv_keep;
                             wgt = alpha * T;
-                            const float keep = 1.0f - last_alpha;
-                            acR = last_alpha * lR + keep * acR; lR = r2.x;
-                            acG = last_alpha * lG + keep * acG; lG = r2.y;
-                            acB = last_alpha * lB + keep * acB; lB = r2.z;
+                            // ac* = colour accumulated BEHIND this splat (normalised by the transmittance in front of it);
+                            // it is advanced past this splat at the end of the block, so no "last colour" state is kept
                             float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB;
-                            if (HAS_D) { acD = last_alpha * lD + keep * acD; lD = r0.w; dLa += (r0.w - acD) * gD; }
-                            if (HAS_A) { acA = last_alpha + keep * acA; dLa += (1.0f - acA) * gA; }  // the alpha channel's "colour" is 1
+                            if (HAS_D) dLa += (r0.w - acD) * gD;
+                            if (HAS_A) dLa += (1.0f - acA) * gA;  // the alpha channel's "colour" is 1
                             dLa *= T;
-                            last_alpha = alpha;
                             dLa += (-T_final * inv_keep) * bg_dot;
+                            acR = alpha * r2.x + keep * acR;
+                            acG = alpha * r2.y + keep * acG;
+                            acB = alpha * r2.z + keep * acB;
+                            if (HAS_D) acD = alpha * r0.w + keep * acD;
+                            if (HAS_A) acA = alpha + keep * acA;
                             g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
                         }
                         const float sxv = g1 * dx, syv = g1 * dy;
