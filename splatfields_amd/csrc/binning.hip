@@ -467,10 +467,10 @@ template <int LO, int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
     constexpr int GROUPS = THREADS / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);                          // [CAP]
-    uint64_t* scratch_key = run_key + CAP;                                           // [GROUPS][1024]
-    uint32_t* run_val = reinterpret_cast<uint32_t*>(scratch_key + GROUPS * 1024);    // [CAP]
-    uint32_t* scratch_val = run_val + CAP;                                           // [GROUPS][1024]
+    // [CAP] keys + [CAP] values.  A group uses the 1024-entry area of the run it is sorting as the scratch of the
+    // network's cross-wavefront stages and then leaves the sorted run there: no separate scratch, twice the occupancy.
+    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
+    uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
     const uint32_t group = threadIdx.x >> 8, tid = threadIdx.x & 255u;
     for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
@@ -484,24 +484,27 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, cons
             __syncthreads();  // scratch reuse
             // Every network size has exactly 3 cross-wavefront (LDS) stages = 6 workgroup barriers, so groups may run
             // differently sized networks side by side: a short last run does not pay for a 1024-network.
-            uint64_t* sk = scratch_key + group * 1024u;
-            uint32_t* sv = scratch_val + group * 1024u;
+            // r < CAP/1024 always (CAP/1024 is a multiple of GROUPS); an idle group (m = 0) sorts padding in its own free slot
             uint64_t* rk = run_key + r * 1024u;
             uint32_t* rv = run_val + r * 1024u;
+            uint64_t k[4]; uint32_t v[4];  // a 256- / 512-network uses the first 1 / 2 of them
             if (m <= 256u) {
-                uint64_t k[1]; uint32_t v[1];
-                load_sort_chunk<256, 1>(b, start + r * 1024u, m, k, v, sk, sv, tid);
-                if (tid < m) { rk[tid] = k[0]; rv[tid] = v[0]; }
+                uint64_t k1[1]; uint32_t v1[1];
+                load_sort_chunk<256, 1>(b, start + r * 1024u, m, k1, v1, rk, rv, tid);
+                k[0] = k1[0]; v[0] = v1[0];
             } else if (m <= 512u) {
-                uint64_t k[2]; uint32_t v[2];
-                load_sort_chunk<512, 2>(b, start + r * 1024u, m, k, v, sk, sv, tid);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) { const uint32_t i = tid * 2 + e; if (i < m) { rk[i] = k[e]; rv[i] = v[e]; } }
+                uint64_t k2[2]; uint32_t v2[2];
+                load_sort_chunk<512, 2>(b, start + r * 1024u, m, k2, v2, rk, rv, tid);
+                k[0] = k2[0]; k[1] = k2[1]; v[0] = v2[0]; v[1] = v2[1];
             } else {
-                uint64_t k[4]; uint32_t v[4];
-                load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, sk, sv, tid);
+                load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, rk, rv, tid);
+            }
+            __syncthreads();  // every wavefront is past the last LDS stage of its network before the area is overwritten
+            const uint32_t per = m <= 256u ? 1u : (m <= 512u ? 2u : 4u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const uint32_t i = tid * 4 + e; if (i < m) { rk[i] = k[e]; rv[i] = v[e]; } }
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = tid * per + e;
+                if ((uint32_t)e < per && i < m) { rk[i] = k[e]; rv[i] = v[e]; }
             }
         }
         __syncthreads();
@@ -527,7 +530,7 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, cons
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    auto lds = [](int cap, int threads) { return (size_t)(cap + threads / 256 * 1024) * 12; };
+    auto lds = [](int cap, int) { return (size_t)cap * 12; };
     hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
     if (max_len >= 0 && max_len <= 1024) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);
@@ -539,9 +542,10 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
         attr_set = true;
     }
     const int rare_grid = tiles < 128 ? tiles : 128;
-    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(max_len >= 0 ? rare_grid : tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
-    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(rare_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
+    // dense scenes put many tiles in this class too: one workgroup per tile (the launch is skipped when no list is this long)
+    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(tiles), dim3(1024), lds(8192, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 8192) return;
     hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(rare_grid), dim3(1024), 0, st, g, b, tiles);
 }

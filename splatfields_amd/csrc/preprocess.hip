@@ -306,6 +306,48 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         }
         __syncthreads();
     }
+    // ---- segmented reduction of every splat's instance slots (fixed order -> deterministic) ----
+    // Splats with many instances (large footprints; dense real scenes) are reduced by the whole wavefront, 64
+    // instances per step + one DPP reduction, instead of serialising hundreds of iterations in one lane.
+    float sum[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sum[k] = 0.f;
+    {
+        const float4* sl_all = reinterpret_cast<const float4*>(slots);
+        const bool vis_in = valid && radius_in > 0;
+        const bool big = vis_in && cnt_in >= 32u;
+        const int lane = lane_id();
+        uint64_t todo = __ballot(big);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= (todo - 1);
+            const uint32_t f = (uint32_t)__shfl((int)first_in, src, 64), c = (uint32_t)__shfl((int)cnt_in, src, 64);
+            float part[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) part[k] = 0.f;
+            for (uint32_t i = lane; i < c; i += 64u) {
+                const float4* sl = sl_all + (size_t)(f + i) * 3;
+                const float4 a = sl[0], b4 = sl[1], c4 = sl[2];
+                part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
+                part[4] += b4.x; part[5] += b4.y; part[6] += b4.z; part[7] += b4.w;
+                part[8] += c4.x; part[9] += c4.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const float tot = __shfl(wave_sum_to_lane63(part[k]), 63, 64);
+                if (lane == src) sum[k] = tot;
+            }
+        }
+        if (vis_in && !big) {
+            const float4* sl = sl_all + (size_t)first_in * 3;
+            for (uint32_t i = 0; i < cnt_in; ++i) {
+                const float4 a = sl[3 * i], b4 = sl[3 * i + 1], c4 = sl[3 * i + 2];
+                sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
+                sum[4] += b4.x; sum[5] += b4.y; sum[6] += b4.z; sum[7] += b4.w;
+                sum[8] += c4.x; sum[9] += c4.y;
+            }
+        }
+    }
     if (valid) {
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
@@ -323,16 +365,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     float3 p = make_float3(0.f, 0.f, 0.f);
     uint8_t flags = 0;
     if (visible) {
-        // ---- segmented reduction of this splat's instance slots (deterministic order) ----
-        float S0 = 0.f, Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dd = 0.f;
-        const uint32_t first = first_in, cnt = cnt_in;
-        const float4* sl = reinterpret_cast<const float4*>(slots) + (size_t)first * 3;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const float4 a = sl[3 * k], b = sl[3 * k + 1], c = sl[3 * k + 2];
-            S0 += a.x; Sx += a.y; Sy += a.z; Sxx += a.w;
-            Sxy += b.x; Syy += b.y; dr += b.z; dg += b.w;
-            db += c.x; dd += c.y;
-        }
+        const float S0 = sum[0], Sx = sum[1], Sy = sum[2], Sxx = sum[3], Sxy = sum[4], Syy = sum[5];
+        const float dr = sum[6], dg = sum[7], db = sum[8], dd = sum[9];
         flags = flags_in;
         const float o = opac_in;
         d_opac = S0;
