@@ -200,120 +200,7 @@ void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStre
         hipLaunchKernelGGL(k_emit<false>, dim3(ch.n_sub), dim3(kBlock), 0, st, v, N, g, b, ch);
 }
 
-// ---- per-tile sort in LDS --------------------------------------------------------------------
-template <int THREADS>
-__device__ __forceinline__ void bitonic_lds(uint64_t* skey, uint32_t* sval, uint32_t n2) {
-    for (uint32_t k = 2; k <= n2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (n2 >> 1); t += THREADS) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                const bool asc = (i & k) == 0;
-                const uint64_t a = skey[i], c = skey[l];
-                if ((a > c) == asc) {
-                    skey[i] = c; skey[l] = a;
-                    const uint32_t va = sval[i]; sval[i] = sval[l]; sval[l] = va;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-__device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
-    uint32_t p = 1;
-    while (p < n) p <<= 1;
-    return p;
-}
-
-// One workgroup per tile; handles list lengths in (MINLEN, CAP].
-template <int CAP, int THREADS, int MINLEN>
-__global__ void __launch_bounds__(THREADS) k_sort_tiles(const Geom g, const Binning b, int n_tiles) {
-    __shared__ uint64_t skey[CAP];
-    __shared__ uint32_t sval[CAP];
-    if (g.total[0] > b.capacity) return;
-    // rare class: a small grid strides over the tiles instead of launching one (mostly idle) workgroup per tile
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
-        const uint32_t start = g.tile_start[tile];
-        const uint32_t n = g.tile_start[tile + 1] - start;
-        if (n <= (uint32_t)MINLEN || n > (uint32_t)CAP) continue;
-        const uint32_t n2 = next_pow2(n);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n2; i += THREADS) {
-            const uint4 en = i < n ? b.ent[start + i] : make_uint4(~0u, ~0u, 0u, 0u);
-            skey[i] = ((uint64_t)en.y << 32) | en.x;
-            sval[i] = en.z;
-        }
-        __syncthreads();
-        bitonic_lds<THREADS>(skey, sval, n2);
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            b.sorted_id[start + i] = sval[i];
-            b.sorted_inst[start + i] = (uint32_t)skey[i];
-        }
-    }
-}
-
-// Lists longer than the LDS capacity: sort CAP-sized chunks in LDS, then merge the runs through the
-// global ping-pong buffers (rank by binary search; keys are unique).  One workgroup per long tile;
-// slow but rare (a tile would need > 8192 overlapping splats).
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <int CAP, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b, int n_tiles) {
-    __shared__ uint64_t skey[CAP];
-    __shared__ uint32_t sval[CAP];
-    if (g.total[0] > b.capacity) return;
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
-    const uint32_t start = g.tile_start[tile];
-    const uint32_t n = g.tile_start[tile + 1] - start;
-    if (n <= (uint32_t)CAP) continue;
-    __syncthreads();
-    uint64_t* k0 = b.keys + start; uint32_t* v0 = b.vals + start;
-    uint64_t* k1 = b.keys_tmp + start; uint32_t* v1 = b.vals_tmp + start;
-    for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
-        const uint32_t m = min((uint32_t)CAP, n - c0);
-        const uint32_t m2 = next_pow2(m);
-        for (uint32_t i = threadIdx.x; i < m2; i += THREADS) {
-            const uint4 en = i < m ? b.ent[start + c0 + i] : make_uint4(~0u, ~0u, 0u, 0u);
-            skey[i] = ((uint64_t)en.y << 32) | en.x;
-            sval[i] = en.z;
-        }
-        __syncthreads();
-        bitonic_lds<THREADS>(skey, sval, m2);
-        for (uint32_t i = threadIdx.x; i < m; i += THREADS) { k0[c0 + i] = skey[i]; v0[c0 + i] = sval[i]; }
-        __syncthreads();
-    }
-    for (uint32_t width = CAP; width < n; width <<= 1) {
-        __threadfence();
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            const uint32_t pair_base = (i / (2 * width)) * (2 * width);
-            const uint32_t mid = min(pair_base + width, n), end = min(pair_base + 2 * width, n);
-            const bool left = i < mid;
-            const uint64_t key = ld_agent(k0 + i);
-            uint32_t lo = left ? mid : pair_base, hi = left ? end : mid;  // search the other run
-            while (lo < hi) {
-                const uint32_t mm = (lo + hi) >> 1;
-                if (ld_agent(k0 + mm) < key) lo = mm + 1; else hi = mm;
-            }
-            const uint32_t rank = lo - (left ? mid : pair_base);
-            const uint32_t pos = pair_base + (i - (left ? pair_base : mid)) + rank;
-            k1[pos] = key;
-            v1[pos] = ld_agent(v0 + i);
-        }
-        uint64_t* tk = k0; k0 = k1; k1 = tk;
-        uint32_t* tv = v0; v0 = v1; v1 = tv;
-    }
-    __threadfence();
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        b.sorted_id[start + i] = ld_agent(v0 + i);
-        b.sorted_inst[start + i] = (uint32_t)ld_agent(k0 + i);
-    }
-    }  // tile loop
-}
-
+// ---- per-tile sort ---------------------------------------------------------------------------------------------
 // ---- register-resident bitonic network (the default path for lists up to 4096 entries) ---------------------
 // 256 threads, E consecutive elements per thread (N = 256*E).  A compare-exchange at distance j is
 //   j < E        : inside one thread's registers,
@@ -459,68 +346,132 @@ __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Bin
     else sort_tile_regs<1024, 4>(b, start, n, skey, sval);
 }
 
-// lists of (LO, CAP] entries: runs of 1024 sorted by the register network into LDS, then ONE multi-way merge pass --
-// keys are unique, so the final position of an entry is its index in its own run plus, for every other run, the
-// number of smaller keys there (binary search in LDS).  The workgroup has one 256-thread group per run (up to 4),
-// all running the same 1024-network side by side, so a 4096-entry list costs one network latency, not four.
+// Sorts n <= CAP entries starting at b.ent[first]: runs of 1024 are sorted by the register network into LDS (one
+// 256-thread group per run, side by side), then ONE multi-way merge pass -- keys are unique, so the final position of an
+// entry is its index in its own run plus, for every other run, the number of smaller keys there (binary search in LDS).
+// A list of 1100 entries costs a 1024- and a 256-network instead of the 2048-network of a power-of-two bitonic sort.
+// emit(rank, key, value) receives every entry with its final rank.  Ends with a workgroup barrier.
+template <int CAP, int THREADS, typename Emit>
+__device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, uint32_t* run_val, Emit&& emit) {
+    constexpr int GROUPS = THREADS / 256;
+    const uint32_t group = threadIdx.x >> 8, tid = threadIdx.x & 255u;
+    const uint32_t n_runs = (n + 1023u) / 1024u;
+    for (uint32_t r0 = 0; r0 < n_runs; r0 += GROUPS) {  // uniform trip count: the barriers below are workgroup-wide
+        const uint32_t r = r0 + group;
+        const uint32_t m = r < n_runs ? min(1024u, n - r * 1024u) : 0u;
+        __syncthreads();  // scratch reuse
+        // Every network size has exactly 3 cross-wavefront (LDS) stages = 6 workgroup barriers, so groups may run
+        // differently sized networks side by side: a short last run does not pay for a 1024-network.  A group uses the
+        // 1024-entry area of its run as the scratch of those stages and then leaves the sorted run there.
+        // r < CAP/1024 always (CAP/1024 is a multiple of GROUPS); an idle group (m = 0) sorts padding in its own free slot.
+        uint64_t* rk = run_key + r * 1024u;
+        uint32_t* rv = run_val + r * 1024u;
+        uint64_t k[4]; uint32_t v[4];  // a 256- / 512-network uses the first 1 / 2 of them
+        if (m <= 256u) {
+            uint64_t k1[1]; uint32_t v1[1];
+            load_sort_chunk<256, 1>(b, first + r * 1024u, m, k1, v1, rk, rv, tid);
+            k[0] = k1[0]; v[0] = v1[0];
+        } else if (m <= 512u) {
+            uint64_t k2[2]; uint32_t v2[2];
+            load_sort_chunk<512, 2>(b, first + r * 1024u, m, k2, v2, rk, rv, tid);
+            k[0] = k2[0]; k[1] = k2[1]; v[0] = v2[0]; v[1] = v2[1];
+        } else {
+            load_sort_chunk<1024, 4>(b, first + r * 1024u, m, k, v, rk, rv, tid);
+        }
+        __syncthreads();  // every wavefront is past the last LDS stage of its network before the area is overwritten
+        const uint32_t per = m <= 256u ? 1u : (m <= 512u ? 2u : 4u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = tid * per + e;
+            if ((uint32_t)e < per && i < m) { rk[i] = k[e]; rv[i] = v[e]; }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+        const uint32_t own = i >> 10;
+        const uint64_t key = run_key[i];
+        uint32_t rank = i & 1023u;
+        for (uint32_t r = 0; r < n_runs; ++r) {
+            if (r == own) continue;
+            const uint64_t* rk = run_key + r * 1024u;
+            uint32_t lo = 0, hi = min(1024u, n - r * 1024u);
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk[mid] < key) lo = mid + 1; else hi = mid; }
+            rank += lo;
+        }
+        emit(rank, key, run_val[i]);
+    }
+    __syncthreads();
+}
+
+// lists of (LO, CAP] entries, one workgroup per tile; LDS = CAP * 12 bytes
 template <int LO, int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
-    constexpr int GROUPS = THREADS / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    // [CAP] keys + [CAP] values.  A group uses the 1024-entry area of the run it is sorting as the scratch of the
-    // network's cross-wavefront stages and then leaves the sorted run there: no separate scratch, twice the occupancy.
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
     uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
-    const uint32_t group = threadIdx.x >> 8, tid = threadIdx.x & 255u;
     for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)LO || n > (uint32_t)CAP) continue;
-        const uint32_t n_runs = (n + 1023u) / 1024u;
-        for (uint32_t r0 = 0; r0 < n_runs; r0 += GROUPS) {  // uniform trip count: the barriers below are workgroup-wide
-            const uint32_t r = r0 + group;
-            const uint32_t m = r < n_runs ? min(1024u, n - r * 1024u) : 0u;
-            __syncthreads();  // scratch reuse
-            // Every network size has exactly 3 cross-wavefront (LDS) stages = 6 workgroup barriers, so groups may run
-            // differently sized networks side by side: a short last run does not pay for a 1024-network.
-            // r < CAP/1024 always (CAP/1024 is a multiple of GROUPS); an idle group (m = 0) sorts padding in its own free slot
-            uint64_t* rk = run_key + r * 1024u;
-            uint32_t* rv = run_val + r * 1024u;
-            uint64_t k[4]; uint32_t v[4];  // a 256- / 512-network uses the first 1 / 2 of them
-            if (m <= 256u) {
-                uint64_t k1[1]; uint32_t v1[1];
-                load_sort_chunk<256, 1>(b, start + r * 1024u, m, k1, v1, rk, rv, tid);
-                k[0] = k1[0]; v[0] = v1[0];
-            } else if (m <= 512u) {
-                uint64_t k2[2]; uint32_t v2[2];
-                load_sort_chunk<512, 2>(b, start + r * 1024u, m, k2, v2, rk, rv, tid);
-                k[0] = k2[0]; k[1] = k2[1]; v[0] = v2[0]; v[1] = v2[1];
-            } else {
-                load_sort_chunk<1024, 4>(b, start + r * 1024u, m, k, v, rk, rv, tid);
-            }
-            __syncthreads();  // every wavefront is past the last LDS stage of its network before the area is overwritten
-            const uint32_t per = m <= 256u ? 1u : (m <= 512u ? 2u : 4u);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t i = tid * per + e;
-                if ((uint32_t)e < per && i < m) { rk[i] = k[e]; rv[i] = v[e]; }
-            }
+        sort_block_lds<CAP, THREADS>(b, start, n, run_key, run_val, [&](uint32_t rank, uint64_t key, uint32_t val) {
+            b.sorted_id[start + rank] = val;
+            b.sorted_inst[start + rank] = (uint32_t)key;
+        });
+    }
+}
+
+// Lists longer than 8192 entries: chunks of 8192 are sorted as above (into the global ping-pong buffer A), then the
+// sorted chunks are merged pairwise through the global buffers (rank by binary search; keys are unique).
+// One workgroup per long tile.
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int CAP, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
+    uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
+    if (g.total[0] > b.capacity) return;
+    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
+        const uint32_t start = g.tile_start[tile];
+        const uint32_t n = g.tile_start[tile + 1] - start;
+        if (n <= (uint32_t)CAP) continue;
+        uint64_t* k0 = b.keys + start; uint32_t* v0 = b.vals + start;
+        uint64_t* k1 = b.keys_tmp + start; uint32_t* v1 = b.vals_tmp + start;
+        for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
+            const uint32_t m = min((uint32_t)CAP, n - c0);
+            sort_block_lds<CAP, THREADS>(b, start + c0, m, run_key, run_val, [&](uint32_t rank, uint64_t key, uint32_t val) {
+                k0[c0 + rank] = key;
+                v0[c0 + rank] = val;
+            });
         }
+        for (uint32_t width = CAP; width < n; width <<= 1) {
+            __threadfence();
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+                const uint32_t pair_base = (i / (2 * width)) * (2 * width);
+                const uint32_t mid = min(pair_base + width, n), end = min(pair_base + 2 * width, n);
+                const bool left = i < mid;
+                const uint64_t key = ld_agent(k0 + i);
+                uint32_t lo = left ? mid : pair_base, hi = left ? end : mid;  // search the other run
+                while (lo < hi) {
+                    const uint32_t mm = (lo + hi) >> 1;
+                    if (ld_agent(k0 + mm) < key) lo = mm + 1; else hi = mm;
+                }
+                const uint32_t rank = lo - (left ? mid : pair_base);
+                const uint32_t pos = pair_base + (i - (left ? pair_base : mid)) + rank;
+                k1[pos] = key;
+                v1[pos] = ld_agent(v0 + i);
+            }
+            uint64_t* tk = k0; k0 = k1; k1 = tk;
+            uint32_t* tv = v0; v0 = v1; v1 = tv;
+        }
+        __threadfence();
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            const uint32_t own = i >> 10;
-            const uint64_t key = run_key[i];
-            uint32_t rank = i & 1023u;
-            for (uint32_t r = 0; r < n_runs; ++r) {
-                if (r == own) continue;
-                const uint64_t* rk = run_key + r * 1024u;
-                uint32_t lo = 0, hi = min(1024u, n - r * 1024u);
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk[mid] < key) lo = mid + 1; else hi = mid; }
-                rank += lo;
-            }
-            b.sorted_id[start + rank] = run_val[i];
-            b.sorted_inst[start + rank] = (uint32_t)key;
+            b.sorted_id[start + i] = ld_agent(v0 + i);
+            b.sorted_inst[start + i] = (uint32_t)ld_agent(k0 + i);
         }
         __syncthreads();
     }
@@ -539,15 +490,15 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4096, 1024));
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
         attr_set = true;
     }
-    const int rare_grid = tiles < 128 ? tiles : 128;
     hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
     // dense scenes put many tiles in this class too: one workgroup per tile (the launch is skipped when no list is this long)
     hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(tiles), dim3(1024), lds(8192, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 8192) return;
-    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(rare_grid), dim3(1024), 0, st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(tiles), dim3(1024), lds(8192, 1024), st, g, b, tiles);
 }
 
 }  // namespace sr
