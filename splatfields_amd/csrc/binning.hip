@@ -1,15 +1,17 @@
 // Per-tile bucketing and sort for gfx950 (replaces the published pipeline's
 // InclusiveSum -> duplicateWithKeys -> 64-bit global radix sort -> identifyTileRanges).
 //
-// MI355X-first design: the sort key is (tile, depth, instance).  The tile digit is resolved by a
-// bucket scatter (per-tile counts are produced by the preprocess kernel, prefix-summed here, so
-// tile ranges come for free), and each tile's list -- 1-2 k entries at 1 M splats / 800x800 -- is
-// then sorted by one workgroup entirely in LDS (160 KiB per CU) on the 64-bit key
-// (depth bits << 32 | instance index).  Instance indices grow with the splat index, so the order is
-// exactly the published "stable sort by depth, ties by splat index", and it is a total order:
-// the result does not depend on the arrival order of the scatter atomics (bit-reproducible).
-// HBM traffic per instance: 12 B scatter write + 12 B sort read + 8 B sorted write, versus
-// 6 radix passes x 24 B for a global 44-bit LSD sort.
+// MI355X-first design: the sort key is (tile, depth, instance).
+//  * The tile digit is resolved by a bucket scatter.  Per-tile counts come from a count matrix [chunk][tile] built with
+//    LDS histograms (no global atomics), prefix-summed along chunks and tiles, which also yields the tile ranges.
+//  * Each tile's list -- ~900 entries at 1 M splats / 800x800, thousands in dense scenes -- is sorted by one workgroup on
+//    the 64-bit key (depth bits << 32 | instance index): a bitonic network held in registers (lane exchanges by DPP /
+//    v_permlane swaps, 3 LDS stages) for runs of <= 1024 entries, and a multi-way rank merge in LDS for longer lists.
+//    Instance indices grow with the splat index, so the order is exactly the published "stable sort by depth, ties by
+//    splat index", and it is a total order: the result does not depend on the arrival order of the scatter
+//    (bit-reproducible).
+// HBM traffic per instance: 16 B scatter write + 16 B sort read + 8 B sorted write, versus 6 radix passes x 24 B for a
+// global 44-bit LSD sort.
 #include "kernels.h"
 #include "expand.h"
 
@@ -200,14 +202,13 @@ void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStre
         hipLaunchKernelGGL(k_emit<false>, dim3(ch.n_sub), dim3(kBlock), 0, st, v, N, g, b, ch);
 }
 
-// ---- per-tile sort ---------------------------------------------------------------------------------------------
-// ---- register-resident bitonic network (the default path for lists up to 4096 entries) ---------------------
+// ---- per-tile sort: register-resident bitonic network ---------------------------------------------------------
 // 256 threads, E consecutive elements per thread (N = 256*E).  A compare-exchange at distance j is
 //   j < E        : inside one thread's registers,
 //   j < 64*E     : with lane (lane ^ j/E) of the same wavefront through a cross-lane shuffle,
 //   otherwise    : with another wavefront through LDS -- exactly 3 such stages for every N.
-// The LDS-only network above moves all 12 bytes/entry through LDS log2(N)(log2(N)+1)/2 times (55 for N=1024)
-// and was LDS-bandwidth bound (rocprofv3: SQ_WAIT_INST_LDS dominant); this one touches LDS 3 times.
+// (A network living entirely in LDS moves all 12 bytes/entry through LDS log2(N)(log2(N)+1)/2 times -- 55 for N = 1024 --
+// and was LDS-bandwidth bound in the first version; this one touches LDS 3 times.)
 // Value of lane (lane ^ D) without touching LDS (ds_bpermute_b32 measured at ~24 cycles per wave-instruction
 // per SIMD on MI355X, DPP adds/moves at ~4, v_permlane*_swap at ~8):
 //   D = 1, 2 : DPP quad_perm          D = 8 : DPP row_ror:8 (rotation by 8 in a row of 16 is xor 8)
