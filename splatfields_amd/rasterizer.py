@@ -124,6 +124,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.sh_coeffs = sh_coeffs
         ctx.n = n
         ctx.opac_shape = tuple(opacities.shape)
+        ctx.in_dtypes = [None if t is None else t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         if n == 0:
@@ -200,7 +201,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sink is not None:
             sink.append(d_col)  # clamp-masked dL/dcolour of this view; dL/dsh is rebuilt from all views by the caller
             d_col = None
-        return d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov, None, None
+        grads = [d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov]
+        # the kernels compute in fp32; hand each gradient back in its input's dtype (fp64 / fp16 callers)
+        grads = [g_ if (g_ is None or dt is None or g_.dtype == dt) else g_.to(dt) for g_, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -223,3 +223,19 @@ def test_backward_variants_without_depth_or_alpha_gradients(hip_device, with_dep
 def test_images_smaller_than_or_barely_above_one_tile(hip_device, w, h):
     sp, cam, st, grads = make_scene(400, w, h, mean_scale=0.2, view=6)
     check_against_oracles(sp, st, grads, hip_device, max_fragile=0.6)  # every splat overlaps every pixel: many near-threshold pairs
+
+
+def test_non_fp32_inputs_are_accepted_and_get_gradients_in_their_dtype(hip_device):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sp, cam, st, grads = make_scene(800, 64, 48, mean_scale=0.06)
+    dev = hip_device
+    rs = GaussianRasterizationSettings(48, 64, st.tanfovx, st.tanfovy, st.bg.to(dev), 1.0, st.viewmatrix.to(dev).double(),
+                                       st.projmatrix.to(dev).double(), 3, st.campos.to(dev), False, False)
+    p = {k: sp[k].to(dev).double().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    c, r, d = GaussianRasterizer(rs)(means3D=p["means3D"], means2D=torch.zeros_like(p["means3D"]), opacities=p["opacities"],
+                                     shs=p["shs"], scales=p["scales"], rotations=p["rotations"])
+    assert c.dtype == torch.float32
+    (c.double() * grads[0].to(dev).double()).sum().backward()
+    assert all(v.grad is not None and v.grad.dtype == torch.float64 for v in p.values())
+    ref, gr = O.fwd_bwd(sp, st, grads[0], None, None, use_sh=True, dtype=torch.float64)
+    assert grad_error(p["means3D"].grad.cpu(), gr["means3D"]) <= GRAD_TOL64
