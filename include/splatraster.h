@@ -125,7 +125,8 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
                long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,
                long long* instances_out, void* hip_stream);
 
-/* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero). */
+/* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero).  `instances` is the capacity the binning
+ * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes. */
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
                 long long instances, const void* image, const int* radii, const float* dL_dcolor,
                 const float* dL_ddepth, const float* dL_dalpha, void* scratch, const SrGrads* grads,

@@ -107,7 +107,11 @@ const char* sr_last_error(void) { return g_last_error.c_str(); }
 size_t sr_geom_bytes(int n, int h, int w) { return sr::carve_geom(nullptr, n, h, w, nullptr); }
 size_t sr_binning_bytes(long long r, int, int) { return sr::carve_binning(nullptr, r, nullptr); }
 size_t sr_image_bytes(int h, int w) { return sr::carve_image(nullptr, h, w, nullptr); }
-size_t sr_backward_scratch_bytes(long long r) { return sr::align_up((size_t)(r > 0 ? r : 1) * sr::kSlotFloats * sizeof(float), 256); }
+// scratch layout: [reached: 1 byte per instance][slots: 48 bytes per instance]
+size_t sr_backward_scratch_bytes(long long r) {
+    const size_t n = (size_t)(r > 0 ? r : 1);
+    return sr::align_up(n, 256) + sr::align_up(n * sr::kSlotFloats * sizeof(float), 256);
+}
 
 }  // extern "C"
 
@@ -219,8 +223,11 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     sr::carve_geom(const_cast<void*>(geom), s.N, v.H, v.W, &g);
     sr::carve_binning(const_cast<void*>(binning), instances, &b);
     sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
-    float* slots = static_cast<float*>(scratch);
-    { StageTimer t_(5, st); sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st); }
+    const size_t n_inst = (size_t)(instances > 0 ? instances : 1);
+    uint8_t* reached = static_cast<uint8_t*>(scratch);
+    float* slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + sr::align_up(n_inst, 256));
+    SR_TRY(check_hip(hipMemsetAsync(reached, 0, n_inst, st), "clear reached flags"));
+    { StageTimer t_(5, st); sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st); }
     SR_TRY(after_launch(view, st, "render_backward"));
     sr::GradsK gr;
     gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
@@ -228,7 +235,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
     gr.shs = s.shs ? grads->dL_dshs : nullptr;
     gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
-    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, gr, st); }
+    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, reached, gr, st); }
     SR_TRY(after_launch(view, st, "preprocess_backward"));
     return 0;
 }

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         carry += all;
         __syncthreads();
     }
-    if (tid == 0) { if (tiles) dst[n] = carry; else g.total[0] = carry; }
+    if (tid == 0) { if (tiles) dst[n] = carry; else { g.total[0] = carry; g.total[2] = 0u; } }
     if (tiles) {  // longest tile list: lets the host skip the launches of the rare long-list sort classes
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));

@@ -47,7 +47,7 @@ struct Geom {
     uint32_t* tile_count;    // [tiles]
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
-    uint32_t* total;         // [0] number of instances, [1] longest tile list
+    uint32_t* total;         // [0] number of instances, [1] longest tile list, [2] sum over tiles of the entries the forward reached
     // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
     uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
     uint32_t* segtot;        // [segments][tiles_padded] column totals per segment of kSegRows chunks
@@ -154,6 +154,17 @@ inline size_t carve_image(void* base, int H, int W, Image* im) {
 // One record of the backward scratch: per tile-splat instance, the tile-reduced moment sums.
 // (S0, Sx, Sy, Sxx | Sxy, Syy, dr, dg | db, ddepth, pad, pad)
 constexpr int kSlotFloats = 12;
+
+#ifdef __HIPCC__
+// Backward bookkeeping mode, decided on the device from what the forward recorded (same expression in both backward
+// kernels): when early termination left a good part of the tile lists unreached (dense scenes), unreached slots are
+// neither written nor read and a `reached` byte per instance says which are valid; when nearly everything was reached
+// (sparse clouds such as the 1 M headline workload) the few unreached slots are zero-filled instead and the per-splat
+// reduction reads every slot without a dependent flag load.
+__device__ __forceinline__ bool use_reached_flags(const uint32_t* total) {
+    return (float)total[2] < 0.8f * (float)total[0];
+}
+#endif
 
 // ---- per-view constants, passed to kernels by value ----------------------------------------
 struct ViewK {

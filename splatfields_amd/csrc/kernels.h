@@ -19,7 +19,7 @@ struct GradsK {
 void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st);
 void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t st);
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
-                                const float* slots, const GradsK& gr, hipStream_t st);
+                                const float* slots, const uint8_t* reached, const GradsK& gr, hipStream_t st);
 // binning.hip
 // true when the image is small enough for the atomic-free count-matrix bucketing
 inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixTiles; }
@@ -32,7 +32,7 @@ void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, cons
                            float* out_color, float* out_depth, float* out_alpha, hipStream_t st);
 void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* slots, hipStream_t st);
+                            float* slots, uint8_t* reached, hipStream_t st);
 
 // knn.hip
 size_t knn_workspace_bytes(int n);

@@ -276,7 +276,8 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 template <bool STAGE_SH, bool SH_TO_COLORS>
 __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
                                                                 const int* __restrict__ radii,
-                                                                const float* __restrict__ slots, const GradsK gr) {
+                                                                const float* __restrict__ slots,
+                                                                const uint8_t* __restrict__ reached, const GradsK gr) {
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = idx < s.N;
@@ -298,6 +299,16 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             q_in = reinterpret_cast<const float4*>(s.rotations)[idx];
             sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
         }
+    }
+    // `reached` bytes of the first 4 instances are requested now, so their latency hides behind the SH staging below
+    // (most splats have <= 4 instances)
+    const bool flags_on = use_reached_flags(g.total);
+    uint32_t reached4 = 0x01010101u;
+    if (flags_on && valid && radius_in > 0) {
+        reached4 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < cnt_in) reached4 |= (uint32_t)reached[first_in + i] << (8 * i);
     }
     if constexpr (STAGE_SH) {
         if (stage_read) {
@@ -326,6 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 #pragma unroll
             for (int k = 0; k < 10; ++k) part[k] = 0.f;
             for (uint32_t i = lane; i < c; i += 64u) {
+                if (flags_on && !reached[f + i]) continue;  // never written by the backward blend: contributes nothing
                 const float4* sl = sl_all + (size_t)(f + i) * 3;
                 const float4 a = sl[0], b4 = sl[1], c4 = sl[2];
                 part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
@@ -341,6 +353,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         if (vis_in && !big) {
             const float4* sl = sl_all + (size_t)first_in * 3;
             for (uint32_t i = 0; i < cnt_in; ++i) {
+                const bool hit = !flags_on || (i < 4u ? ((reached4 >> (8 * i)) & 0xffu) != 0u : reached[first_in + i] != 0);
+                if (!hit) continue;
                 const float4 a = sl[3 * i], b4 = sl[3 * i + 1], c4 = sl[3 * i + 2];
                 sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
                 sum[4] += b4.x; sum[5] += b4.y; sum[6] += b4.z; sum[7] += b4.w;
@@ -551,15 +565,15 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
-                                const float* slots, const GradsK& gr, hipStream_t st) {
+                                const float* slots, const uint8_t* reached, const GradsK& gr, hipStream_t st) {
     const int nb = (s.N + kBlock - 1) / kBlock;
     if (nb <= 0) return;
     const bool to_colors = s.shs && !gr.shs && gr.colors;
     const bool stage = s.shs && v.sh_coeffs == 16 && (gr.shs || (to_colors && v.sh_degree >= 2));
-    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
-    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
-    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
-    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, gr);
+    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
+    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
+    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
+    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
 }
 
 }  // namespace sr

@@ -111,6 +111,16 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             }
         }
     }
+    {   // entries of this tile's list the forward reached (max over its pixels): input of use_reached_flags()
+        uint32_t wl = last;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+        __shared__ uint32_t s_last[4];
+        __syncthreads();
+        if (lane == 0) s_last[wave] = wl;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&g.total[2], max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3])));
+    }
     if (inside) {
         const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
         out_color[pix] = Cr + T * v.bg[0];
@@ -139,7 +149,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                                                             const float* __restrict__ dL_dcolor,
                                                             const float* __restrict__ dL_ddepth,
                                                             const float* __restrict__ dL_dalpha,
-                                                            float* __restrict__ slots) {
+                                                            float* __restrict__ slots, uint8_t* __restrict__ reached) {
     __shared__ float4 s_r0[kBwdBatch];
     __shared__ float4 s_r1[kBwdBatch];
     __shared__ float4 s_r2[kBwdBatch];
@@ -179,10 +189,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
     float4* slot4 = reinterpret_cast<float4*>(slots);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // list entries behind every pixel's last contributor receive no gradient
-    for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
-        const size_t inst = b.sorted_inst[start + i];
-        slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
+    // List entries behind every pixel's last contributor receive no gradient.  With `flags` their slots are not written
+    // at all and their `reached` byte stays 0 (the buffer is cleared before the launch); otherwise they are zero-filled.
+    const bool flags = use_reached_flags(g.total);
+    if (!flags) {
+        for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
+            const size_t inst = b.sorted_inst[start + i];
+            slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
+        }
     }
 
     float T = T_final;
@@ -286,6 +300,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                 slot4[inst * 3 + q] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
                                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
             }
+            if (flags) reached[inst] = 1;
         }
         __syncthreads();
     }
@@ -293,14 +308,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
 void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* slots, hipStream_t st) {
+                            float* slots, uint8_t* reached, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
     const bool d = dL_ddepth != nullptr, a = dL_dalpha != nullptr;
-    if (d && a) hipLaunchKernelGGL((k_render_backward<true, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
-    else if (d) hipLaunchKernelGGL((k_render_backward<true, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
-    else if (a) hipLaunchKernelGGL((k_render_backward<false, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
-    else hipLaunchKernelGGL((k_render_backward<false, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    if (d && a) hipLaunchKernelGGL((k_render_backward<true, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
+    else if (d) hipLaunchKernelGGL((k_render_backward<true, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
+    else if (a) hipLaunchKernelGGL((k_render_backward<false, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
+    else hipLaunchKernelGGL((k_render_backward<false, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
 }
 
 }  // namespace sr

@@ -191,7 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col)
-            scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.instances), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.capacity), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col))
             _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
