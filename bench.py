@@ -109,6 +109,7 @@ def main():
     stats = {"R": 0.0, "vis": 0.0, "n": 0}
 
     gather = world > 1 and use_sh and args.dp_mode == "gather"
+    state = {"gather": gather}
 
     def one_step_gather(step_idx: int, record: bool):
         step_cams = [cams[(step_idx * world + r) % len(cams)] for r in range(world)]
@@ -125,7 +126,7 @@ def main():
             stats["n"] += 1
 
     def one_step(step_idx: int, record: bool = False):
-        if gather:
+        if state["gather"]:
             return one_step_gather(step_idx, record)
         cam = cams[(step_idx * world + rank) % len(cams)]
         rs = GaussianRasterizationSettings(
@@ -156,6 +157,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if gather:
+        # make sure every rank can run the gather exchange; otherwise all ranks fall back to the plain all-reduce together
+        ok = torch.ones(1, device=dev)
+        try:
+            one_step(0)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: gather exchange failed ({e!r}); falling back to --dp-mode allreduce", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            state["gather"] = False
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -203,7 +216,7 @@ def main():
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
                                f"1 view per GPU per step, colour+depth+alpha outputs, fwd+bwd"
                                + ((", RCCL all-gather of colour gradients + all-reduce of the other per-splat gradients"
-                                   if gather else ", RCCL sum all-reduce of per-splat gradients") if world > 1 else ""),
+                                   if state["gather"] else ", RCCL sum all-reduce of per-splat gradients") if world > 1 else ""),
                    "splats": N, "width": W, "height": H, "views_per_step": world,
                    "visible_splats": vis, "tile_instances": R},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
