@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     }
 
     float T = T_final;
-    float acR = 0.f, acG = 0.f, acB = 0.f, acD = 0.f, acA = 0.f;       // colour accumulated behind
+    float behind_g = T_final * bg_dot;  // (colour accumulated behind the current splat, incl. background) . upstream gradient
 
     for (int top = bmax; top > 0; top -= kBwdBatch) {
         const int cnt = min(kBwdBatch, top);
@@ -246,22 +246,17 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
                         float g1 = 0.f, wgt = 0.f;
                         if (contrib) {
-                            const float keep = 1.0f - alpha;
-                            const float inv_keep = __builtin_amdgcn_rcpf(keep);  // v_rcp_f32, 1 ulp
-                            T = T * inv_keep;
+                            const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
+                            T = T * inv_keep;   // transmittance in front of this splat
                             wgt = alpha * T;
-                            // ac* = colour accumulated BEHIND this splat (normalised by the transmittance in front of it);
-                            // it is advanced past this splat at the end of the block, so no "last colour" state is kept
-                            float dLa = (r2.x - acR) * gR + (r2.y - acG) * gG + (r2.z - acB) * gB;
-                            if (HAS_D) dLa += (r0.w - acD) * gD;
-                            if (HAS_A) dLa += (1.0f - acA) * gA;  // the alpha channel's "colour" is 1
-                            dLa *= T;
-                            dLa += (-T_final * inv_keep) * bg_dot;
-                            acR = alpha * r2.x + keep * acR;
-                            acG = alpha * r2.y + keep * acG;
-                            acB = alpha * r2.z + keep * acB;
-                            if (HAS_D) acD = alpha * r0.w + keep * acD;
-                            if (HAS_A) acA = alpha + keep * acA;
+                            // dL/dalpha_i = T_i (c_i . g) - (sum_{j behind i} w_j (c_j . g) + T_final (bg . g)) / (1 - alpha_i).
+                            // The upstream gradient g is constant along the list, so the "colour behind" enters only through
+                            // its dot product with g: ONE scalar recurrence (behind_g) instead of one per channel.
+                            float cg = r2.x * gR + r2.y * gG + r2.z * gB;
+                            if (HAS_D) cg += r0.w * gD;
+                            if (HAS_A) cg += gA;  // the alpha channel's "colour" is 1 for every splat
+                            const float dLa = T * cg - inv_keep * behind_g;
+                            behind_g = fmaf(wgt, cg, behind_g);
                             g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
                         }
                         const float sxv = g1 * dx, syv = g1 * dy;
