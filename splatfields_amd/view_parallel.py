@@ -3,11 +3,12 @@
 The reference renders the views of one iteration in a Python loop over the *same* splat tensors and
 averages their losses before one backward (train.py:158-169, :242, :252).  Views are independent, so
 they shard: one process per GPU, splat tensors replicated, rank r renders views r, r+G, r+2G, ...;
-each rank back-propagates its local mean loss, then ONE sum all-reduce per gradient tensor over
-RCCL/xGMI (`torch.distributed`, backend "nccl") followed by a 1/G scale reproduces the gradient of
-the mean over all views.  No packing copy: each dense gradient tensor is reduced in place (the SH
-gradient, 192 B/splat, dominates the payload: 236 B/splat with SH, 56 B/splat with precomputed
-colours -- SURVEY.md §8e).
+each rank back-propagates its local mean loss, then a sum all-reduce over RCCL/xGMI
+(`torch.distributed`, backend "nccl") followed by a 1/G scale reproduces the gradient of the mean
+over all views.  The SH gradient (192 B/splat, the bulk of the 236 B/splat payload; 56 B/splat
+with precomputed colours -- SURVEY.md §8e) is reduced in place without a packing copy; the small
+geometric gradients share one packed buffer and one collective.  `sh_gather_step` avoids moving the
+SH gradient at all.
 
 Densification statistics (`viewspace_points.grad`, `radii`) are per view; this harness keeps the
 reference's "last view wins" rule (train.py:178, :282, :307) on every rank for its own last view.
@@ -25,24 +26,55 @@ def shard_views(views: Sequence, rank: int, world: int) -> list:
     return [v for i, v in enumerate(views) if i % world == rank]
 
 
+# Gradient tensors below this size are packed into one flat buffer and reduced by ONE collective: at 1 M splats the four
+# geometric gradients are 4-16 MB each, where a collective's fixed cost (launch + 8-rank handshake) is a visible fraction of
+# its transfer time; the SH gradient (192 MB) is reduced on its own, without a packing copy.
+PACK_BELOW_BYTES = 64 << 20
+
+
+def pack_gradients(grads: Sequence[torch.Tensor]):
+    """One flat buffer holding ``grads`` back to back (one `cat` kernel) and, per tensor, a view of its segment."""
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    views, off = [], 0
+    for g in grads:
+        views.append(flat[off:off + g.numel()].view(g.shape))
+        off += g.numel()
+    return flat, views
+
+
 def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None) -> None:
-    """In-place sum all-reduce of every ``.grad`` followed by the 1/world scale.
-    Collectives are issued asynchronously back to back (largest tensor first, so its ring starts
-    while the small ones are queued) and waited together."""
+    """Mean over ranks of every ``.grad``: large tensors are all-reduced in place (largest first, so its ring starts while
+    the rest is queued), the small ones travel packed in one buffer and ``p.grad`` is re-pointed at its segment.
+    All collectives are issued asynchronously back to back and waited together."""
     if world <= 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    grads.sort(key=lambda g: -g.numel())
+    params = [p for p in params if p.grad is not None]
+    big = sorted((p for p in params if p.grad.numel() * p.grad.element_size() >= PACK_BELOW_BYTES),
+                 key=lambda p: -p.grad.numel())
+    small = [p for p in params if p.grad.numel() * p.grad.element_size() < PACK_BELOW_BYTES]
     # RCCL averages in the collective itself (no extra pass over 236 B/splat); gloo (CPU tests) has no AVG
     avg = dist.get_backend(group) == "nccl"
     op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-    works = [dist.all_reduce(g, op=op, group=group, async_op=True) for g in grads]
+    works = [dist.all_reduce(p.grad, op=op, group=group, async_op=True) for p in big]
+    by_dtype = {}
+    for p in small:
+        by_dtype.setdefault(p.grad.dtype, []).append(p)
+    packed = []
+    for ps in by_dtype.values():
+        flat, views = pack_gradients([p.grad for p in ps])
+        works.append(dist.all_reduce(flat, op=op, group=group, async_op=True))
+        packed.append((ps, flat, views))
     for w in works:
         w.wait()
     if not avg:
         scale = 1.0 / world
-        for g in grads:
-            g.mul_(scale)
+        for p in big:
+            p.grad.mul_(scale)
+        for _, flat, _ in packed:
+            flat.mul_(scale)
+    for ps, _, views in packed:
+        for p, v in zip(ps, views):
+            p.grad = v
 
 
 def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
@@ -97,18 +129,22 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     campos_all = torch.stack([c.camera_center.to(device=dev, dtype=torch.float32).reshape(3) for c in cams])
     if world > 1:
         gathered = torch.empty(world, len(mine), n, 3, dtype=torch.float32, device=dev)
-        works = [dist.all_gather_into_tensor(gathered.view(-1), dcol_local.view(-1), group=group, async_op=True)]
-        works += [dist.all_reduce(params[k].grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
-                  for k in sorted(names, key=lambda q: -params[q].numel())]
-        for w in works:
-            w.wait()
+        # the collectives run in issue order on RCCL's stream: the all-gather first (the SH rebuild needs it), then ONE
+        # all-reduce of the four geometric gradients packed back to back (44 B/splat), which overlaps the SH rebuild
+        gather_work = dist.all_gather_into_tensor(gathered.view(-1), dcol_local.view(-1), group=group, async_op=True)
+        flat, views = pack_gradients([params[k].grad for k in names])
+        reduce_work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         # gathered[r, slot] is view r + slot*world
         order = [r + sl * world for r in range(world) for sl in range(len(mine))]
         dcol_all = gathered.reshape(world * len(mine), n, 3)
         campos_used = campos_all if order == list(range(V)) else campos_all[torch.tensor(order, device=dev)]
+        gather_work.wait()
+        params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
+        reduce_work.wait()
+        for k, v in zip(names, views):
+            params[k].grad = v
     else:
-        dcol_all, campos_used = dcol_local, campos_all
-    params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
+        params["shs"].grad = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
 
 
 def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss: Callable, *, rank: int = None,
@@ -139,10 +175,16 @@ def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss:
         for p in params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
-                 for p in sorted(params, key=lambda q: -q.numel())]
-        local = local.clone()
-        works.append(dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        big = sorted((p for p in params if p.grad.numel() * p.grad.element_size() >= PACK_BELOW_BYTES or p.grad.dtype != local.dtype),
+                     key=lambda q: -q.numel())
+        small = [p for p in params if not any(p is b for b in big)]
+        works = [dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=True) for p in big]
+        # the small gradients and the scalar loss share one buffer and one collective
+        flat, views = pack_gradients([p.grad for p in small] + [local.reshape(1)])
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
         for w in works:
             w.wait()
+        for p, v in zip(small, views):
+            p.grad = v
+        local = views[-1].reshape(())
     return local
