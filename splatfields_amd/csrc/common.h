@@ -232,10 +232,14 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
 // skip decisions.  Returns false when the pair is skipped (power > 0 or alpha < 1/255).
 // The conic in the per-splat record is pre-multiplied by log2(e) (and so is tau), so exp(power) is one v_exp_f32.
 constexpr float kLog2e = 1.4426950408889634f;
-__device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_o, float& G, float& alpha) {
-    const float power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;  // = ln-power * log2(e)
+__device__ __forceinline__ void pair_alpha_terms(float dx, float dy, const float4 con_o, float& power, float& G, float& alpha) {
+    power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;  // = ln-power * log2(e)
     G = __builtin_amdgcn_exp2f(power);
     alpha = fminf(kAlphaMax, con_o.w * G);
+}
+__device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_o, float& G, float& alpha) {
+    float power;
+    pair_alpha_terms(dx, dy, con_o, power, G, alpha);
     return (power <= 0.0f) && (alpha >= kAlphaMin);
 }
 

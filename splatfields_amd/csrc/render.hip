@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         }
         __syncthreads();
         const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
-        if (__ballot(live) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
             // 64 staged entries at a time: one lane tests one entry against this wavefront's 8x8 pixels, the
             // ballot is a scalar bit mask, and the wavefront walks its set bits -- uniform control flow, the
             // LDS address of the next record is known without a dependent index load, the body is branch-free.
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                 const int el = c + lane;
                 const int ec = el < cnt ? el : cnt - 1;
                 const bool ok = el < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
-                uint64_t m = __ballot(ok);
+                uint64_t m = __builtin_amdgcn_ballot_w64(ok);
                 const uint32_t pos0 = (base - start) + (uint32_t)c + 1u;
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     T = blend ? test_T : T;
                     last = blend ? pos0 + (uint32_t)bit : last;
                 }
-                if (__ballot(live) == 0ull) break;
+                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
             }
         }
     }
@@ -224,14 +224,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                 const int el = c + lane;
                 const int ec = el < cnt ? el : cnt - 1;
                 const bool ok = el < cnt && (top - 1 - el) < wmax && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
-                uint64_t m = __ballot(ok);
+                uint64_t m = __builtin_amdgcn_ballot_w64(ok);
                 // 4 list entries per step (taken from the scalar bit mask): their 4 x 10 per-lane partial sums
                 // are reduced together by a butterfly (v_permlane32_swap, v_permlane16_swap, then 4 DPP steps
                 // inside each row of 16 lanes): 100 cross-lane adds per 4 entries instead of 4 x 60.
                 while (m) {
                     float pv[4][10];
                     int ent[4];
-                    bool any = false;
+                    uint64_t any = 0ull;  // wave-level: kept as a scalar mask, no per-lane flag
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bool live = m != 0ull;
@@ -241,8 +241,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         const int pos = top - 1 - e;
                         const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                         const float dx = r0.x - pxf, dy = r0.y - pyf;
-                        float G, alpha;
-                        const bool contrib = pair_alpha(dx, dy, r1, G, alpha) && live && (pos < my_last);
+                        float power, G, alpha;
+                        pair_alpha_terms(dx, dy, r1, power, G, alpha);
+                        const bool c_pow = power <= 0.0f, c_alpha = alpha >= kAlphaMin, c_pos = pos < my_last;
+                        const bool contrib = c_pow && c_alpha && live && c_pos;
+                        // wave-level "anyone might contribute" (a superset is fine, it only gates the reduction): AND of the two
+                        // float-compare masks, which are the v_cmp's own scalar results (a ballot of the combined per-lane flag
+                        // costs v_cndmask + v_cmp per entry)
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c_pow) & __builtin_amdgcn_ballot_w64(c_alpha);
                         // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
                         float g1 = 0.f, wgt = 0.f;
                         if (contrib) {
@@ -262,9 +268,9 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         const float sxv = g1 * dx, syv = g1 * dy;
                         pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
                         pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = HAS_D ? wgt * gD : 0.f;
-                        any = any || contrib;
+                        any |= live ? cm : 0ull;
                     }
-                    if (__ballot(any) == 0ull) continue;
+                    if (any == 0ull) continue;
                     float red[10];
                     red[9] = 0.f;
 #pragma unroll
@@ -273,6 +279,9 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         const float z23 = swap32_add(pv[2][k], pv[3][k]);   // lanes 0-31: entry 2, lanes 32-63: entry 3
                         float w = swap16_add(z01, z23);                     // rows: 0 -> entry 0, 1 -> entry 2, 2 -> entry 1, 3 -> entry 3
                         w = dpp_add<0xB1>(w); w = dpp_add<0x4E>(w); w = dpp_add<0x124>(w); w = dpp_add<0x128>(w);
+                        // keep the last add next to its DPP move (one fused v_add_f32_dpp) instead of letting it sink into the
+                        // lane-0-of-each-row store below as v_mov 0 + v_mov_dpp + v_add
+                        asm volatile("" : "+v"(w));
                         red[k] = w;
                     }
                     const int row = lane >> 4;
