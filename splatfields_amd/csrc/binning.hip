@@ -133,7 +133,32 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         __syncthreads();
         if (lane == 0) s_wave[w] = vmax;
         __syncthreads();
-        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; }
+        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; s_wave[0] = m; }
+        __syncthreads();
+        // Launch order of the blend kernels: longest lists first (longest-processing-time-first keeps the tail of the
+        // launch short: 2500 tiles are only ~1.6 rounds of resident workgroups).  Counting sort into 256 linear length
+        // classes; the order inside a class is arbitrary (it only affects scheduling, never results).
+        __shared__ uint32_t s_hist[256];
+        const uint32_t longest = max(s_wave[0], 1u);
+        if (tid < 256) s_hist[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const uint32_t len = dst[i + 1] - dst[i];   // written by this workgroup above (barriers in between)
+            atomicAdd(&s_hist[255u - (uint32_t)(((uint64_t)len * 255u) / longest)], 1u);
+        }
+        __syncthreads();
+        if (w == 0) {  // exclusive prefix over the 256 classes: 4 per lane
+            uint32_t c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            const uint32_t excl = wave_inclusive_scan(sum) - sum;
+            s_hist[4 * lane] = excl; s_hist[4 * lane + 1] = excl + c0; s_hist[4 * lane + 2] = excl + c0 + c1;
+            s_hist[4 * lane + 3] = excl + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const uint32_t len = dst[i + 1] - dst[i];
+            g.tile_order[atomicAdd(&s_hist[255u - (uint32_t)(((uint64_t)len * 255u) / longest)], 1u)] = (uint32_t)i;
+        }
     }
 }
 

@@ -47,6 +47,7 @@ struct Geom {
     uint32_t* tile_count;    // [tiles]
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
+    uint32_t* tile_order;    // [tiles] tiles by decreasing list length (coarse classes): launch order of the blend kernels
     uint32_t* total;         // [0] number of instances, [1] longest tile list, [2] sum over tiles of the entries the forward reached
     // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
     uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
@@ -117,7 +118,7 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     t.flags = c.take<uint8_t>(n);
     t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
     t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);
-    t.tile_cursor = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
+    t.tile_cursor = c.take<uint32_t>(tiles); t.tile_order = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
     t.cnt = t.segtot = t.segbase = nullptr;
     if (tiles <= (size_t)kMaxMatrixTiles) {
         const Chunking ch = make_chunking(N, (int)tiles);

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     __shared__ float4 s_r2[kFwdBatch];
 
     if (g.total[0] > b.capacity) return;  // uniform: see sr_forward
-    const int tile = blockIdx.x;
+    const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = wave_id(), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
     __shared__ uint32_t s_max[4];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = wave_id(), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
