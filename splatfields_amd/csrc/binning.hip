@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Bin
     __shared__ uint64_t skey[1024];
     __shared__ uint32_t sval[1024];
     if (g.total[0] > b.capacity) return;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = g.tile_order[blockIdx.x];  // longest lists first
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
     if (n == 0u || n > 1024u) return;
@@ -436,7 +436,8 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, cons
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
     uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
+    for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
+        const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)LO || n > (uint32_t)CAP) continue;
@@ -459,7 +460,8 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
     uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
-    for (uint32_t tile = blockIdx.x; tile < (uint32_t)n_tiles; tile += gridDim.x) {
+    for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
+        const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)CAP) continue;
@@ -512,12 +514,14 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     if (max_len >= 0 && max_len <= 1024) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 2048) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4096, 1024));
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
