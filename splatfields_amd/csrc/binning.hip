@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         if (idx < N) {
             touched = g.touched[idx];
             rect = g.rect[idx];
-            if (touched) dbits = __float_as_uint(g.rec[4 * (size_t)idx].w);  // view depth > 0.2: float bits sort as integers
+            dbits = g.depth_bits[idx];  // view depth > 0.2: float bits sort as integers
         }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // leading barrier protects LDS reuse

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
-    uint32_t touched = 0;
+    uint32_t touched = 0, depth_bits = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
 
     // issue this splat's own loads first, then the staged SH block: everything is in flight together
@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                     }
                     float4* rec = g.rec + 4 * (size_t)idx;
                     rec[0] = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
+                    depth_bits = __float_as_uint(pv.z);
                     rec[1] = make_float4(cA * kLog2e, cB * kLog2e, cC * kLog2e, opac);
                     rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
                 }
@@ -219,6 +220,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         radii[idx] = out_radius;
         g.rect[idx] = rect;
         g.touched[idx] = touched;
+        g.depth_bits[idx] = depth_bits;
         g.flags[idx] = flags;
     }
 
