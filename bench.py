@@ -53,13 +53,13 @@ def stage_bytes(stage: str, n: int, vis: float, R: float, hw: int, c_in: int) ->
         # read mean 12 + scale 12 + rot 16 + opacity 4 + colour input; write radii 4; visible: 40 B state
         "preprocess": n * (44 + c_in + 4) + vis * 40,
         "scan": n / 256 * 8,
-        # read depth/rect/count per splat, write one 16-byte (key, value) record per instance
-        "emit": n * 16 + R * 16,
-        # read the 16-byte record, write sorted id 4 + instance 4
-        "sort_tiles": R * 24,
+        # read depth/rect/count per splat, write one 8-byte key (depth bits, splat index) per instance
+        "emit": n * 16 + R * 8,
+        # read the 8-byte key, write the sorted splat index
+        "sort_tiles": R * 12,
         # read id 4 + gather 40 B state per instance; write rgb 12, depth 4, alpha 4, final_T 4, n_contrib 4 per pixel
         "render_forward": R * 44 + hw * 28,
-        # read id 4 + slot index 4 + 40 B state, write 40 B gradient moments per instance;
+        # read id 4 + first-instance offset 4 + 40 B state, write 40 B gradient moments per instance;
         # read dL/drgb 12, dL/ddepth 4, dL/dalpha 4, final_T 4, n_contrib 4 per pixel
         "render_backward": R * 88 + hw * 28,
         # re-read inputs, read 40 B per instance, write all gradients

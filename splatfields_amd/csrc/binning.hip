@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
             uint32_t slot;
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
-            b.ent[slot] = make_uint4(base + i, s_depth[e], first_splat + (uint32_t)e, 0u);
+            b.ent[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(first_splat + (uint32_t)e);
         });
     }
 }
@@ -271,18 +271,19 @@ __device__ __forceinline__ uint32_t lane_xor_d(uint32_t x, int d) {
     }
 }
 
-template <int E>
-__device__ __forceinline__ void exchange_select(uint64_t& k, uint32_t& v, uint64_t pk, uint32_t pv, bool keep_min) {
-    // keys are unique except for the +inf padding, where either choice is fine: one compare, mask xnor, 3 selects
+// The sort key is (view-depth bits << 32) | splat index: unique inside a tile (a splat appears once per tile), equal
+// depths are ordered by splat index like the stable radix sort of the published pipeline.  The payload IS the low half
+// of the key, so the network moves 8 bytes per entry and nothing else.
+__device__ __forceinline__ void exchange_select(uint64_t& k, uint64_t pk, bool keep_min) {
+    // keys are unique except for the +inf padding, where either choice is fine: one compare, mask xnor, 2 selects
     const bool take = (pk < k) == keep_min;
     k = take ? pk : k;
-    v = take ? pv : v;
 }
 
 // `tid` is the thread's index inside its 256-thread group (several groups of one workgroup may run the same network
 // side by side on different data; the barriers inside are workgroup-wide, so all groups must call it together).
 template <int N, int E>
-__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint64_t* skey, uint32_t* sval, uint32_t tid) {
+__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint64_t* skey, uint32_t tid) {
 #pragma unroll
     for (int kk = 2; kk <= N; kk <<= 1) {
 #pragma unroll
@@ -295,9 +296,7 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E],
                         const bool asc = (i & kk) == 0;
                         const bool swap = (k[e] > k[e | j]) == asc;
                         const uint64_t ka = k[e], kb = k[e | j];
-                        const uint32_t va = v[e], vb = v[e | j];
                         k[e] = swap ? kb : ka; k[e | j] = swap ? ka : kb;
-                        v[e] = swap ? vb : va; v[e | j] = swap ? va : vb;
                     }
                 }
             } else if (j < 64 * E) {
@@ -305,26 +304,25 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E],
                 const bool lower = (tid & d) == 0;
                 // kk >= 2j > E here, so the direction bit (i & kk) depends on the thread only
                 const bool keep_min = lower == (((tid * E) & kk) == 0);
-                uint32_t plo[E], phi[E], pv[E];
+                uint32_t plo[E], phi[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     plo[e] = lane_xor_d((uint32_t)k[e], d);
                     phi[e] = lane_xor_d((uint32_t)(k[e] >> 32), d);
-                    pv[e] = lane_xor_d(v[e], d);
                 }
 #pragma unroll
-                for (int e = 0; e < E; ++e) exchange_select<E>(k[e], v[e], ((uint64_t)phi[e] << 32) | plo[e], pv[e], keep_min);
+                for (int e = 0; e < E; ++e) exchange_select(k[e], ((uint64_t)phi[e] << 32) | plo[e], keep_min);
             } else {
                 __syncthreads();
 #pragma unroll
-                for (int e = 0; e < E; ++e) { skey[tid * E + e] = k[e]; sval[tid * E + e] = v[e]; }
+                for (int e = 0; e < E; ++e) skey[tid * E + e] = k[e];
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const uint32_t i = tid * E + e;
                     const bool asc = (i & kk) == 0;
                     const bool lower = (i & j) == 0;
-                    exchange_select<E>(k[e], v[e], skey[i ^ j], sval[i ^ j], lower == asc);
+                    exchange_select(k[e], skey[i ^ j], lower == asc);
                 }
             }
         }
@@ -334,51 +332,46 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[E], uint32_t (&v)[E],
 // Loads up to N = 256*E consecutive entries (padding with +inf keys), sorts them in registers; afterwards
 // thread t holds the entries of rank t*E .. t*E+E-1.
 template <int N, int E>
-__device__ __forceinline__ void load_sort_chunk(const Binning& b, uint32_t first, uint32_t m, uint64_t (&k)[E], uint32_t (&v)[E],
-                                                uint64_t* scratch_key, uint32_t* scratch_val, uint32_t tid) {
+__device__ __forceinline__ void load_sort_chunk(const Binning& b, uint32_t first, uint32_t m, uint64_t (&k)[E], uint64_t* scratch_key, uint32_t tid) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = tid * E + e;
-        const uint4 en = i < m ? b.ent[first + i] : make_uint4(~0u, ~0u, 0u, 0u);
-        k[e] = ((uint64_t)en.y << 32) | en.x;
-        v[e] = en.z;
+        k[e] = i < m ? b.ent[first + i] : ~0ull;
     }
-    bitonic_regs<N, E>(k, v, scratch_key, scratch_val, tid);
+    bitonic_regs<N, E>(k, scratch_key, tid);
 }
 
 template <int N, int E>
-__device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start, uint32_t n, uint64_t* skey, uint32_t* sval) {
+__device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start, uint32_t n, uint64_t* skey) {
     uint64_t k[E];
-    uint32_t v[E];
-    load_sort_chunk<N, E>(b, start, n, k, v, skey, sval, threadIdx.x);
+    load_sort_chunk<N, E>(b, start, n, k, skey, threadIdx.x);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = threadIdx.x * E + e;
-        if (i < n) { b.sorted_id[start + i] = v[e]; b.sorted_inst[start + i] = (uint32_t)k[e]; }
+        if (i < n) b.sorted_id[start + i] = (uint32_t)k[e];
     }
 }
 
-// lists of 1..1024 entries: one register network, one workgroup (256 threads) per tile, LDS 12 KiB
+// lists of 1..1024 entries: one register network, one workgroup (256 threads) per tile, LDS 8 KiB
 __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Binning b) {
     __shared__ uint64_t skey[1024];
-    __shared__ uint32_t sval[1024];
     if (g.total[0] > b.capacity) return;
     const uint32_t tile = g.tile_order[blockIdx.x];  // longest lists first
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
     if (n == 0u || n > 1024u) return;
-    if (n <= 256u) sort_tile_regs<256, 1>(b, start, n, skey, sval);
-    else if (n <= 512u) sort_tile_regs<512, 2>(b, start, n, skey, sval);
-    else sort_tile_regs<1024, 4>(b, start, n, skey, sval);
+    if (n <= 256u) sort_tile_regs<256, 1>(b, start, n, skey);
+    else if (n <= 512u) sort_tile_regs<512, 2>(b, start, n, skey);
+    else sort_tile_regs<1024, 4>(b, start, n, skey);
 }
 
 // Sorts n <= CAP entries starting at b.ent[first]: runs of 1024 are sorted by the register network into LDS (one
 // 256-thread group per run, side by side), then ONE multi-way merge pass -- keys are unique, so the final position of an
 // entry is its index in its own run plus, for every other run, the number of smaller keys there (binary search in LDS).
 // A list of 1100 entries costs a 1024- and a 256-network instead of the 2048-network of a power-of-two bitonic sort.
-// emit(rank, key, value) receives every entry with its final rank.  Ends with a workgroup barrier.
+// emit(rank, key) receives every entry with its final rank.  Ends with a workgroup barrier.
 template <int CAP, int THREADS, typename Emit>
-__device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, uint32_t* run_val, Emit&& emit) {
+__device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, Emit&& emit) {
     constexpr int GROUPS = THREADS / 256;
     const uint32_t group = threadIdx.x >> 8, tid = threadIdx.x & 255u;
     const uint32_t n_runs = (n + 1023u) / 1024u;
@@ -391,25 +384,24 @@ __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first,
         // 1024-entry area of its run as the scratch of those stages and then leaves the sorted run there.
         // r < CAP/1024 always (CAP/1024 is a multiple of GROUPS); an idle group (m = 0) sorts padding in its own free slot.
         uint64_t* rk = run_key + r * 1024u;
-        uint32_t* rv = run_val + r * 1024u;
-        uint64_t k[4]; uint32_t v[4];  // a 256- / 512-network uses the first 1 / 2 of them
+        uint64_t k[4];  // a 256- / 512-network uses the first 1 / 2 of them
         if (m <= 256u) {
-            uint64_t k1[1]; uint32_t v1[1];
-            load_sort_chunk<256, 1>(b, first + r * 1024u, m, k1, v1, rk, rv, tid);
-            k[0] = k1[0]; v[0] = v1[0];
+            uint64_t k1[1];
+            load_sort_chunk<256, 1>(b, first + r * 1024u, m, k1, rk, tid);
+            k[0] = k1[0];
         } else if (m <= 512u) {
-            uint64_t k2[2]; uint32_t v2[2];
-            load_sort_chunk<512, 2>(b, first + r * 1024u, m, k2, v2, rk, rv, tid);
-            k[0] = k2[0]; k[1] = k2[1]; v[0] = v2[0]; v[1] = v2[1];
+            uint64_t k2[2];
+            load_sort_chunk<512, 2>(b, first + r * 1024u, m, k2, rk, tid);
+            k[0] = k2[0]; k[1] = k2[1];
         } else {
-            load_sort_chunk<1024, 4>(b, first + r * 1024u, m, k, v, rk, rv, tid);
+            load_sort_chunk<1024, 4>(b, first + r * 1024u, m, k, rk, tid);
         }
         __syncthreads();  // every wavefront is past the last LDS stage of its network before the area is overwritten
         const uint32_t per = m <= 256u ? 1u : (m <= 512u ? 2u : 4u);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t i = tid * per + e;
-            if ((uint32_t)e < per && i < m) { rk[i] = k[e]; rv[i] = v[e]; }
+            if ((uint32_t)e < per && i < m) rk[i] = k[e];
         }
     }
     __syncthreads();
@@ -424,27 +416,23 @@ __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first,
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk[mid] < key) lo = mid + 1; else hi = mid; }
             rank += lo;
         }
-        emit(rank, key, run_val[i]);
+        emit(rank, key);
     }
     __syncthreads();
 }
 
-// lists of (LO, CAP] entries, one workgroup per tile; LDS = CAP * 12 bytes
+// lists of (LO, CAP] entries, one workgroup per tile; LDS = CAP * 8 bytes
 template <int LO, int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
-    uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
     for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
         const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)LO || n > (uint32_t)CAP) continue;
-        sort_block_lds<CAP, THREADS>(b, start, n, run_key, run_val, [&](uint32_t rank, uint64_t key, uint32_t val) {
-            b.sorted_id[start + rank] = val;
-            b.sorted_inst[start + rank] = (uint32_t)key;
-        });
+        sort_block_lds<CAP, THREADS>(b, start, n, run_key, [&](uint32_t rank, uint64_t key) { b.sorted_id[start + rank] = (uint32_t)key; });
     }
 }
 
@@ -458,21 +446,17 @@ template <int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const Binning b, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
-    uint32_t* run_val = reinterpret_cast<uint32_t*>(run_key + CAP);
     if (g.total[0] > b.capacity) return;
     for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
         const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
         if (n <= (uint32_t)CAP) continue;
-        uint64_t* k0 = b.keys + start; uint32_t* v0 = b.vals + start;
-        uint64_t* k1 = b.keys_tmp + start; uint32_t* v1 = b.vals_tmp + start;
+        uint64_t* k0 = b.keys + start;
+        uint64_t* k1 = b.keys_tmp + start;
         for (uint32_t c0 = 0; c0 < n; c0 += CAP) {
             const uint32_t m = min((uint32_t)CAP, n - c0);
-            sort_block_lds<CAP, THREADS>(b, start + c0, m, run_key, run_val, [&](uint32_t rank, uint64_t key, uint32_t val) {
-                k0[c0 + rank] = key;
-                v0[c0 + rank] = val;
-            });
+            sort_block_lds<CAP, THREADS>(b, start + c0, m, run_key, [&](uint32_t rank, uint64_t key) { k0[c0 + rank] = key; });
         }
         for (uint32_t width = CAP; width < n; width <<= 1) {
             __threadfence();
@@ -490,17 +474,12 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
                 const uint32_t rank = lo - (left ? mid : pair_base);
                 const uint32_t pos = pair_base + (i - (left ? pair_base : mid)) + rank;
                 k1[pos] = key;
-                v1[pos] = ld_agent(v0 + i);
             }
             uint64_t* tk = k0; k0 = k1; k1 = tk;
-            uint32_t* tv = v0; v0 = v1; v1 = tv;
         }
         __threadfence();
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            b.sorted_id[start + i] = ld_agent(v0 + i);
-            b.sorted_inst[start + i] = (uint32_t)ld_agent(k0 + i);
-        }
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) b.sorted_id[start + i] = (uint32_t)ld_agent(k0 + i);
         __syncthreads();
     }
 }
@@ -509,7 +488,7 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    auto lds = [](int cap, int) { return (size_t)cap * 12; };
+    auto lds = [](int cap, int) { return (size_t)cap * 8; };
     hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
     if (max_len >= 0 && max_len <= 1024) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);

@@ -36,7 +36,8 @@ constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampT
 struct Geom {
     // [N][4] one 64-byte, 64-byte-aligned record per splat, so a gather touches exactly one cache line:
     //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) * log2(e) [support: d^T Q' d <= tau; < 0: never visible], view depth)
-    //   q1 = (conic A, B, C scaled by log2(e) = Q', opacity)      q2 = (r, g, b, unused)      q3 = unused
+    //   q1 = (conic A, B, C scaled by log2(e) = Q', opacity)      q2 = (r, g, b, unused)
+    //   q3 = (bits: tile rect xmin | ymin << 16, bits: rect width, unused, unused)  -- instance index of (splat, tile)
     float4* rec;
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
     uint32_t* touched;   // [N] instances emitted by this splat
@@ -76,15 +77,13 @@ inline Chunking make_chunking(int N, int tiles) {
 }
 
 struct Binning {
-    uint4* ent;          // [R] bucketed per tile, unsorted: (key lo = instance index, key hi = depth bits, splat index, 0)
-                         //     -- ONE 16-byte store per instance from the scatter
-    uint64_t* keys;      // [R] ping-pong pair A of the long-list merge path
-    uint32_t* vals;      // [R]
-    uint64_t* keys_tmp;  // [R] ping-pong pair B
-    uint32_t* vals_tmp;  // [R]
-    uint32_t* sorted_id;   // [R] splat index, per tile front-to-back
-    uint32_t* sorted_inst; // [R] instance index (slot of the backward scratch)
-    uint32_t capacity;     // instances the arrays above were carved for; stage-2 kernels exit if total > capacity
+    uint64_t* ent;       // [R] bucketed per tile, unsorted: sort key = (view-depth bits << 32) | splat index
+                         //     -- ONE 8-byte store per instance from the scatter; the payload is the key's low half
+    uint64_t* keys;      // [R] ping-pong buffer A of the long-list merge path
+    uint64_t* keys_tmp;  // [R] ping-pong buffer B
+    uint32_t* sorted_id; // [R] splat index, per tile front-to-back.  The instance index (slot of the backward scratch) is
+                         //     not stored: offsets[splat] + row-major position of the tile inside the splat's tile rect
+    uint32_t capacity;   // instances the arrays above were carved for; stage-2 kernels exit if total > capacity
 };
 
 struct Image {
@@ -135,10 +134,10 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     Carver c{static_cast<char*>(base), 0};
     const size_t r = (size_t)(R > 0 ? R : 1);
     Binning t;
-    t.ent = c.take<uint4>(r);
-    t.keys = c.take<uint64_t>(r); t.vals = c.take<uint32_t>(r);
-    t.keys_tmp = c.take<uint64_t>(r); t.vals_tmp = c.take<uint32_t>(r);
-    t.sorted_id = c.take<uint32_t>(r); t.sorted_inst = c.take<uint32_t>(r);
+    t.ent = c.take<uint64_t>(r);
+    t.keys = c.take<uint64_t>(r);
+    t.keys_tmp = c.take<uint64_t>(r);
+    t.sorted_id = c.take<uint32_t>(r);
     t.capacity = (uint32_t)(R > 0 ? R : 0);
     if (b) *b = t;
     return align_up(c.off, 256);

@@ -214,9 +214,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                     depth_bits = __float_as_uint(pv.z);
                     rec[1] = make_float4(cA * kLog2e, cB * kLog2e, cC * kLog2e, opac);
                     rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
-                    // the unused quarter is written too: a 64-byte line with a 16-byte hole leaves the L2 as a partial
-                    // (masked) write, which costs more than the 16 extra bytes (0.087 -> 0.078 ms for this kernel)
-                    rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
+                    // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
+                    // partial write, which costs more than the 16 bytes (0.087 -> 0.078 ms for this kernel).
+                    rec[3] = make_float4(__uint_as_float((uint32_t)xmin | ((uint32_t)ymin << 16)), __uint_as_float((uint32_t)(xmax - xmin)), 0.f, 0.f);
                 }
             }
         }

@@ -154,7 +154,6 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     __shared__ float4 s_r0[kBwdBatch];
     __shared__ float4 s_r1[kBwdBatch];
     __shared__ float4 s_r2[kBwdBatch];
-    __shared__ uint32_t s_inst[kBwdBatch];
     __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
     __shared__ uint32_t s_max[4];
 
@@ -195,7 +194,9 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     const bool flags = use_reached_flags(g.total);
     if (!flags) {
         for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
-            const size_t inst = b.sorted_inst[start + i];
+            const uint32_t id = b.sorted_id[start + i];
+            const ushort4 rc = g.rect[id];
+            const size_t inst = g.offsets[id] + (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
             slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
         }
     }
@@ -205,14 +206,21 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
     for (int top = bmax; top > 0; top -= kBwdBatch) {
         const int cnt = min(kBwdBatch, top);
+        // instance index (slot of the gradient scratch) of this thread's list entry = the splat's first instance + row-major
+        // position of this tile inside the splat's tile rect (which rides in the record's fourth quarter).  The offsets
+        // gather is issued last and consumed only after the blend loop, so its latency is never waited for.
+        uint32_t inst_first = 0u, inst_local = 0u;
         if ((int)threadIdx.x < cnt) {
             const uint32_t pos = start + (uint32_t)(top - 1 - (int)threadIdx.x);
             const uint32_t id = b.sorted_id[pos];
             const float4* rec = g.rec + 4 * (size_t)id;
-            s_r0[threadIdx.x] = rec[0];
-            s_r1[threadIdx.x] = rec[1];
-            s_r2[threadIdx.x] = rec[2];
-            s_inst[threadIdx.x] = b.sorted_inst[pos];
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+            inst_first = g.offsets[id];
+            s_r0[threadIdx.x] = r0;
+            s_r1[threadIdx.x] = r1;
+            s_r2[threadIdx.x] = r2;
+            const uint32_t xy = __float_as_uint(r3.x), rw = __float_as_uint(r3.y);
+            inst_local = ((uint32_t)ty - (xy >> 16)) * rw + ((uint32_t)tx - (xy & 0xffffu));
         }
         {
             float4* acc = &s_acc[0][0][0];
@@ -298,7 +306,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int e = threadIdx.x;
-            const size_t inst = s_inst[e];
+            const size_t inst = (size_t)inst_first + inst_local;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const float4 a0 = s_acc[0][e][q], a1 = s_acc[1][e][q], a2 = s_acc[2][e][q], a3 = s_acc[3][e][q];

@@ -52,16 +52,23 @@ __device__ __forceinline__ float3 sh_dir_grad(int deg, float x, float y, float z
     return d;
 }
 
+template <bool STAGE>  // STAGE: K == 16 -> the workgroup's contiguous 48 KiB of coefficients arrive through LDS (coalesced 16-byte loads)
 __global__ void __launch_bounds__(kBlock) k_sh_forward(int N, int K, int deg, const float* __restrict__ means3D, const float* __restrict__ shs,
                                                        const float* __restrict__ campos, float* __restrict__ colors, unsigned char* __restrict__ clamped) {
+    __shared__ float4 s_sh[STAGE ? kBlock * kShRowF4 : 1];
     const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if constexpr (STAGE) {
+        const size_t first = (size_t)blockIdx.x * kBlock;
+        stage_sh_in(s_sh, shs, first, min(kBlock, N - (int)first));
+        __syncthreads();
+    }
     if (idx >= N) return;
     float dx = means3D[3 * (size_t)idx] - campos[0], dy = means3D[3 * (size_t)idx + 1] - campos[1], dz = means3D[3 * (size_t)idx + 2] - campos[2];
     const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     dx *= il; dy *= il; dz *= il;
     float B[16];
     sh_basis16(deg, dx, dy, dz, B);
-    const float* sh = shs + (size_t)idx * K * 3;
+    const float* sh = STAGE ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4]) : shs + (size_t)idx * K * 3;
     const int nb = (deg + 1) * (deg + 1);
     float r = 0.f, g = 0.f, b = 0.f;
     for (int k = 0; k < nb; ++k) { r += B[k] * sh[3 * k]; g += B[k] * sh[3 * k + 1]; b += B[k] * sh[3 * k + 2]; }
@@ -141,7 +148,11 @@ __global__ void __launch_bounds__(kBlock) k_sh_backward(int N, int K, int deg, i
 
 void launch_sh_forward(int N, int K, int deg, const float* means3D, const float* shs, const float* campos, float* colors,
                        unsigned char* clamped, hipStream_t st) {
-    if (N > 0) hipLaunchKernelGGL(k_sh_forward, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, means3D, shs, campos, colors, clamped);
+    if (N <= 0) return;
+    if (K == 16 && deg >= 2)  // below degree 2 only <= 48 of a splat's 192 bytes are needed
+        hipLaunchKernelGGL(k_sh_forward<true>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, means3D, shs, campos, colors, clamped);
+    else
+        hipLaunchKernelGGL(k_sh_forward<false>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, means3D, shs, campos, colors, clamped);
 }
 
 void launch_sh_backward(int N, int K, int deg, int V, const float* means3D, const float* shs, const float* campos, const float* dcol,
