@@ -36,7 +36,7 @@ constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampT
 struct Geom {
     // [N][4] one 64-byte, 64-byte-aligned record per splat, so a gather touches exactly one cache line:
     //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) * log2(e) [support: d^T Q' d <= tau; < 0: never visible], view depth)
-    //   q1 = (conic A, B, C scaled by log2(e) = Q', opacity)      q2 = (r, g, b, unused)
+    //   q1 = (p, s, q, -log2 o): completed-square factors of Q' = conic * log2(e), see pair_alpha_unclamped()      q2 = (r, g, b, 1/o)
     //   q3 = (bits: tile rect xmin | ymin << 16, bits: rect width, unused, unused)  -- instance index of (splat, tile)
     float4* rec;
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
@@ -229,19 +229,23 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
-// The alpha of one (pixel, splat) pair -- shared by forward and backward so both make the same
-// skip decisions.  Returns false when the pair is skipped (power > 0 or alpha < 1/255).
-// The conic in the per-splat record is pre-multiplied by log2(e) (and so is tau), so exp(power) is one v_exp_f32.
+// The alpha of one (pixel, splat) pair -- the same instruction sequence in forward and backward, so both make the same
+// skip decision (alpha < 1/255).  The per-splat record holds the exponent in completed-square form, in log2 units:
+//   -0.5 d^T Q d * log2(e) + log2(o) = -(p (dx + s dy))^2 - (q dy)^2 - nlo,
+//   p = sqrt(log2e/2 * c/det), s = -b/c, q = sqrt(log2e/2 / c), nlo = -log2(o)        (cov2D = [[a, b], [b, c]])
+// i.e. 5 multiply-adds and ONE v_exp_f32 give opacity * exp(power); the exponent is a negated sum of squares, so the
+// published "skip if power > 0" guard (a defence against rounding in the expanded quadratic form) can never fire here.
 constexpr float kLog2e = 1.4426950408889634f;
-__device__ __forceinline__ void pair_alpha_terms(float dx, float dy, const float4 con_o, float& power, float& G, float& alpha) {
-    power = -0.5f * (con_o.x * dx * dx + con_o.z * dy * dy) - con_o.y * dx * dy;  // = ln-power * log2(e)
-    G = __builtin_amdgcn_exp2f(power);
-    alpha = fminf(kAlphaMax, con_o.w * G);
+__device__ __forceinline__ float pair_alpha_unclamped(float dx, float dy, const float4 f) {
+    const float t = f.x * fmaf(f.y, dy, dx), u = f.z * dy;
+    const float w = fmaf(u, u, fmaf(t, t, f.w));
+    return __builtin_amdgcn_exp2f(-w);   // = opacity * G
 }
-__device__ __forceinline__ bool pair_alpha(float dx, float dy, const float4 con_o, float& G, float& alpha) {
-    float power;
-    pair_alpha_terms(dx, dy, con_o, power, G, alpha);
-    return (power <= 0.0f) && (alpha >= kAlphaMin);
+// Q' = conic * log2(e) back from the factors (the support test works on the quadratic form)
+__device__ __forceinline__ void conic_from_factors(const float4 f, float& A, float& B, float& C) {
+    A = 2.0f * f.x * f.x;
+    B = f.y * A;
+    C = fmaf(2.0f * f.z, f.z, f.y * B);
 }
 
 // Exact (up to a safety margin) test: is there a point of the 8x8 pixel-centre box starting at (sx, sy) where
@@ -259,7 +263,9 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
     const float x0 = sx - r0.x, x1 = x0 + (kSub - 1), y0 = sy - r0.y, y1 = y0 + (kSub - 1);  // box relative to the centre
     const bool in_x = x0 <= 0.0f && x1 >= 0.0f, in_y = y0 <= 0.0f && y1 >= 0.0f;
     if (in_x && in_y) return true;
-    const float A = r1.x, B2 = 2.0f * r1.y, C = r1.z;
+    float A, B, C;
+    conic_from_factors(r1, A, B, C);
+    const float B2 = 2.0f * B;
     const float inv_a = __builtin_amdgcn_rcpf(A), inv_c = __builtin_amdgcn_rcpf(C);
     float fmin_ = edge_min(A, B2, C, inv_c, x0, y0, y1);
     fmin_ = fminf(fmin_, edge_min(A, B2, C, inv_c, x1, y0, y1));

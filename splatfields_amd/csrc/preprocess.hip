@@ -212,8 +212,11 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                     float4* rec = g.rec + 4 * (size_t)idx;
                     rec[0] = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
                     depth_bits = __float_as_uint(pv.z);
-                    rec[1] = make_float4(cA * kLog2e, cB * kLog2e, cC * kLog2e, opac);
-                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+                    // exponent factors (common.h, pair_alpha_unclamped): all well conditioned, c >= 0.3 by the dilation
+                    const float inv_c = 1.0f / c;
+                    rec[1] = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
+                                         opac > 0.0f ? -__log2f(opac) : 0.0f);
+                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, opac > 0.0f ? 1.0f / opac : 0.0f);
                     // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
                     // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
                     // partial write, which costs more than the 16 bytes (0.087 -> 0.078 ms for this kernel).

@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     m &= ~(1ull << bit);
                     const int e = c + bit;
                     const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
-                    float G, alpha;
-                    const bool hit = pair_alpha(r0.x - pxf, r0.y - pyf, r1, G, alpha) && live;
+                    const float alpha = fminf(kAlphaMax, pair_alpha_unclamped(r0.x - pxf, r0.y - pyf, r1));
+                    const bool hit = (alpha >= kAlphaMin) && live;
                     const float test_T = T * (1.0f - alpha);
                     const bool stop = hit && (test_T < kTStop);
                     const bool blend = hit != stop;  // stop implies hit: one compare, a mask xor
@@ -249,14 +249,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         const int pos = top - 1 - e;
                         const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                         const float dx = r0.x - pxf, dy = r0.y - pyf;
-                        float power, G, alpha;
-                        pair_alpha_terms(dx, dy, r1, power, G, alpha);
-                        const bool c_pow = power <= 0.0f, c_alpha = alpha >= kAlphaMin, c_pos = pos < my_last;
-                        const bool contrib = c_pow && c_alpha && live && c_pos;
-                        // wave-level "anyone might contribute" (a superset is fine, it only gates the reduction): AND of the two
-                        // float-compare masks, which are the v_cmp's own scalar results (a ballot of the combined per-lane flag
-                        // costs v_cndmask + v_cmp per entry)
-                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c_pow) & __builtin_amdgcn_ballot_w64(c_alpha);
+                        const float oG = pair_alpha_unclamped(dx, dy, r1);   // opacity * G, same sequence as the forward
+                        const float alpha = fminf(kAlphaMax, oG);
+                        const float G = oG * r2.w;                            // r2.w = 1 / opacity
+                        const bool c_alpha = alpha >= kAlphaMin, c_pos = pos < my_last;
+                        const bool contrib = c_alpha && live && c_pos;
+                        // wave-level "anyone might contribute" (a superset is fine, it only gates the reduction): the float
+                        // compare's own scalar mask (a ballot of the combined per-lane flag costs v_cndmask + v_cmp per entry)
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c_alpha);
                         // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
                         float g1 = 0.f, wgt = 0.f;
                         if (contrib) {
