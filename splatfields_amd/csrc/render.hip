@@ -34,6 +34,18 @@ typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 
 // x, y hold two different quantities per lane.  Returns r with r[l] = x[l] + x[l+32] for l < 32 and
 // r[l] = y[l-32] + y[l] for l >= 32 (one v_permlane32_swap + one add): each half-wave now owns one quantity.
+// mask ? a : b with the lane mask held in a scalar register pair (v_cndmask_b32 takes it directly)
+__device__ __forceinline__ float mask_select(uint64_t mask, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ uint32_t mask_select(uint64_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 __device__ __forceinline__ float swap32_add(float x, float y) {
     const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
@@ -66,11 +78,16 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     const uint64_t lt = lanemask_lt();
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
-    uint32_t last = 0;
-    bool live = inside;  // pixel still accumulating (not yet stopped by T < 1e-4)
+    // Pixels still accumulating (not yet stopped by T < 1e-4) are tracked as a SCALAR 64-bit mask: all the skip / stop /
+    // blend logic of an entry is mask arithmetic on the scalar unit (v_cmp results are scalar masks already), and the only
+    // per-lane selects left are the two v_cndmask below.  `last` = number of list entries in front of the one that stopped
+    // the pixel (the whole list if it never stopped): the backward replays entries [0, last) -- entries behind a pixel's
+    // true last contributor fail the alpha test there exactly as they did here, so the looser bound changes no result.
+    uint64_t livem = __builtin_amdgcn_ballot_w64(inside);
+    uint32_t last = inside ? end - start : 0u;
 
     for (uint32_t base = start; base < end; base += kFwdBatch) {
-        if (__syncthreads_count(live) == 0) break;  // also fences LDS reuse
+        if (__syncthreads_count(livem != 0ull) == 0) break;  // also fences LDS reuse
         const uint32_t i = base + threadIdx.x;
         if (i < end) {
             const uint32_t id = b.sorted_id[i];
@@ -81,7 +98,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         }
         __syncthreads();
         const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
-        if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+        if (livem != 0ull) {
             // 64 staged entries at a time: one lane tests one entry against this wavefront's 8x8 pixels, the
             // ballot is a scalar bit mask, and the wavefront walks its set bits -- uniform control flow, the
             // LDS address of the next record is known without a dependent index load, the body is branch-free.
@@ -91,24 +108,24 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                 const int ec = el < cnt ? el : cnt - 1;
                 const bool ok = el < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
                 uint64_t m = __builtin_amdgcn_ballot_w64(ok);
-                const uint32_t pos0 = (base - start) + (uint32_t)c + 1u;
+                const uint32_t pos0 = (base - start) + (uint32_t)c;
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
                     m &= ~(1ull << bit);
                     const int e = c + bit;
                     const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                     const float alpha = fminf(kAlphaMax, pair_alpha_unclamped(r0.x - pxf, r0.y - pyf, r1));
-                    const bool hit = (alpha >= kAlphaMin) && live;
                     const float test_T = T * (1.0f - alpha);
-                    const bool stop = hit && (test_T < kTStop);
-                    const bool blend = hit != stop;  // stop implies hit: one compare, a mask xor
-                    live = live && !stop;
-                    const float w = blend ? alpha * T : 0.0f;
+                    const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & livem;
+                    const uint64_t stopm = __builtin_amdgcn_ballot_w64(test_T < kTStop) & hitm;
+                    const uint64_t blendm = hitm ^ stopm;  // stop implies hit
+                    livem &= ~stopm;
+                    const float w = mask_select(blendm, alpha * T, 0.0f);
                     Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r0.w, w, D);
-                    T = blend ? test_T : T;
-                    last = blend ? pos0 + (uint32_t)bit : last;
+                    T = mask_select(blendm, test_T, T);
+                    if (stopm != 0ull) last = mask_select(stopm, pos0 + (uint32_t)bit, last);  // rare: once per pixel at most
                 }
-                if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+                if (livem == 0ull) break;
             }
         }
     }
