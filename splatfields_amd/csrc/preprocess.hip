@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                     const float inv_c = 1.0f / c;
                     rec[1] = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
                                          opac > 0.0f ? -__log2f(opac) : 0.0f);
-                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, opac > 0.0f ? 1.0f / opac : 0.0f);
+                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
                     // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
                     // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
                     // partial write, which costs more than the 16 bytes (0.087 -> 0.078 ms for this kernel).
@@ -392,10 +392,11 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         const float dr = sum[6], dg = sum[7], db = sum[8], dd = sum[9];
         flags = flags_in;
         const float o = opac_in;
-        d_opac = S0;
+        // the six geometric sums arrive multiplied by the opacity (k_render_backward accumulates o G dL/dalpha)
+        d_opac = o > 0.0f ? S0 / o : 0.0f;
         d_rgb = make_float3(dr, dg, db);
         // conic gradients; .y is half of the true dL/dB (off-diagonal counted once, used twice below)
-        const float dcon_x = -0.5f * o * Sxx, dcon_y = -0.5f * o * Sxy, dcon_z = -0.5f * o * Syy;
+        const float dcon_x = -0.5f * Sxx, dcon_y = -0.5f * Sxy, dcon_z = -0.5f * Syy;
 
         p = p_in;
         const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
@@ -425,8 +426,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const float det_inv = 1.0f / denom;
             const float A = c * det_inv, B = -b * det_inv, C = a * det_inv;
             // dL/d(NDC mean): (0.5 W, 0.5 H) scaled, the convention scene/gaussian_model.py:427-438 consumes
-            d_m2d.x = -o * (A * Sx + B * Sy) * (0.5f * v.W);
-            d_m2d.y = -o * (B * Sx + C * Sy) * (0.5f * v.H);
+            d_m2d.x = -(A * Sx + B * Sy) * (0.5f * v.W);
+            d_m2d.y = -(B * Sx + C * Sy) * (0.5f * v.H);
         }
         const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;

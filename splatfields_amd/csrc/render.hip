@@ -168,9 +168,11 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                                                             const float* __restrict__ dL_ddepth,
                                                             const float* __restrict__ dL_dalpha,
                                                             float* __restrict__ slots, uint8_t* __restrict__ reached) {
-    __shared__ float4 s_r0[kBwdBatch];
-    __shared__ float4 s_r1[kBwdBatch];
-    __shared__ float4 s_r2[kBwdBatch];
+    // slot kBwdBatch is a sentinel record whose exponent offset is +inf (alpha = 0): the dummy entries of an incomplete
+    // group of 4 point at it and contribute nothing without any special-casing in the loop
+    __shared__ float4 s_r0[kBwdBatch + 1];
+    __shared__ float4 s_r1[kBwdBatch + 1];
+    __shared__ float4 s_r2[kBwdBatch + 1];
     __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
     __shared__ uint32_t s_max[4];
 
@@ -218,6 +220,11 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         }
     }
 
+    if (threadIdx.x == 0) {
+        s_r0[kBwdBatch] = zero4;
+        s_r1[kBwdBatch] = make_float4(0.f, 0.f, 0.f, __builtin_inff());
+        s_r2[kBwdBatch] = zero4;
+    }
     float T = T_final;
     float behind_g = T_final * bg_dot;  // (colour accumulated behind the current splat, incl. background) . upstream gradient
 
@@ -259,41 +266,39 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                     uint64_t any = 0ull;  // wave-level: kept as a scalar mask, no per-lane flag
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const bool live = m != 0ull;
-                        const int e = live ? c + (int)__builtin_ctzll(m) : 0;
+                        // fewer than 4 entries left in the mask: the sentinel record (contributes nothing, stores nothing)
+                        const int e = m != 0ull ? c + (int)__builtin_ctzll(m) : kBwdBatch;
                         m &= (m - 1);  // stays 0 once empty
-                        ent[q] = live ? e : -1;
-                        const int pos = top - 1 - e;
+                        ent[q] = e;
                         const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                         const float dx = r0.x - pxf, dy = r0.y - pyf;
                         const float oG = pair_alpha_unclamped(dx, dy, r1);   // opacity * G, same sequence as the forward
-                        const float alpha = fminf(kAlphaMax, oG);
-                        const float G = oG * r2.w;                            // r2.w = 1 / opacity
-                        const bool c_alpha = alpha >= kAlphaMin, c_pos = pos < my_last;
-                        const bool contrib = c_alpha && live && c_pos;
-                        // wave-level "anyone might contribute" (a superset is fine, it only gates the reduction): the float
-                        // compare's own scalar mask (a ballot of the combined per-lane flag costs v_cndmask + v_cmp per entry)
-                        const uint64_t cm = __builtin_amdgcn_ballot_w64(c_alpha);
-                        // g1 / wgt stay 0 in lanes that do not contribute; the 10 partial sums are products of them
-                        float g1 = 0.f, wgt = 0.f;
-                        if (contrib) {
-                            const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
-                            T = T * inv_keep;   // transmittance in front of this splat
-                            wgt = alpha * T;
-                            // dL/dalpha_i = T_i (c_i . g) - (sum_{j behind i} w_j (c_j . g) + T_final (bg . g)) / (1 - alpha_i).
-                            // The upstream gradient g is constant along the list, so the "colour behind" enters only through
-                            // its dot product with g: ONE scalar recurrence (behind_g) instead of one per channel.
-                            float cg = r2.x * gR + r2.y * gG + r2.z * gB;
-                            if (HAS_D) cg += r0.w * gD;
-                            if (HAS_A) cg += gA;  // the alpha channel's "colour" is 1 for every splat
-                            const float dLa = T * cg - inv_keep * behind_g;
-                            behind_g = fmaf(wgt, cg, behind_g);
-                            g1 = G * dLa;  // gradients pass through the min(0.99, .) clamp, as upstream
-                        }
+                        // Who contributes is decided on the scalar unit (oG >= 1/255 is the forward's alpha >= 1/255: the
+                        // 0.99 clamp does not move that threshold).  Everyone else gets alpha = G = 0, which makes every
+                        // product below 0 and leaves T and behind_g unchanged (1/(1-0) = 1 exactly): no divergent branch, so
+                        // the four entries of a step form one basic block whose LDS reads and arithmetic interleave freely.
+                        const uint64_t cm = __builtin_amdgcn_ballot_w64(oG >= kAlphaMin) & __builtin_amdgcn_ballot_w64((top - 1 - e) < my_last);
+                        any |= cm;
+                        const float oGc = mask_select(cm, oG, 0.0f);
+                        const float alpha = __builtin_amdgcn_fmed3f(oGc, 0.0f, kAlphaMax);   // min(0.99, o G), o G >= 0
+                        const float inv_keep = __builtin_amdgcn_rcpf(1.0f - alpha);  // v_rcp_f32, 1 ulp
+                        T = T * inv_keep;   // transmittance in front of this splat
+                        const float wgt = alpha * T;
+                        // dL/dalpha_i = T_i (c_i . g) - (sum_{j behind i} w_j (c_j . g) + T_final (bg . g)) / (1 - alpha_i).
+                        // The upstream gradient g is constant along the list, so the "colour behind" enters only through
+                        // its dot product with g: ONE scalar recurrence (behind_g) instead of one per channel.
+                        float cg = HAS_A ? gA : 0.0f;  // the alpha channel's "colour" is 1 for every splat
+                        if (HAS_D) cg = fmaf(r0.w, gD, cg);
+                        cg = fmaf(r2.z, gB, cg); cg = fmaf(r2.y, gG, cg); cg = fmaf(r2.x, gR, cg);
+                        const float dLa = T * cg - inv_keep * behind_g;
+                        behind_g = fmaf(wgt, cg, behind_g);
+                        // opacity * G * dL/dalpha: the six geometric sums carry the factor `opacity` (k_preprocess_backward
+                        // divides it out of dL/dopacity instead of multiplying it into the other five);
+                        // gradients pass through the min(0.99, .) clamp, as upstream
+                        const float g1 = oGc * dLa;
                         const float sxv = g1 * dx, syv = g1 * dy;
                         pv[q][0] = g1; pv[q][1] = sxv; pv[q][2] = syv; pv[q][3] = sxv * dx; pv[q][4] = sxv * dy; pv[q][5] = syv * dy;
                         pv[q][6] = wgt * gR; pv[q][7] = wgt * gG; pv[q][8] = wgt * gB; pv[q][9] = HAS_D ? wgt * gD : 0.f;
-                        any |= live ? cm : 0ull;
                     }
                     if (any == 0ull) continue;
                     float red[10];
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                     const int row = lane >> 4;
                     const int q_of_row = ((row & 1) << 1) | (row >> 1);
                     const int e_mine = q_of_row == 0 ? ent[0] : (q_of_row == 1 ? ent[1] : (q_of_row == 2 ? ent[2] : ent[3]));
-                    if ((lane & 15) == 0 && e_mine >= 0) {
+                    if ((lane & 15) == 0 && e_mine < kBwdBatch) {
                         s_acc[wave][e_mine][0] = make_float4(red[0], red[1], red[2], red[3]);
                         s_acc[wave][e_mine][1] = make_float4(red[4], red[5], red[6], red[7]);
                         s_acc[wave][e_mine][2] = make_float4(red[8], red[9], 0.f, 0.f);
