@@ -42,6 +42,8 @@ struct Geom {
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
     uint32_t* touched;   // [N] instances emitted by this splat
     uint32_t* offsets;   // [N] exclusive prefix of `touched`
+    float* dcol_ddir;    // [9][N] (SH path, degree > 0) d colour_c / d unit-direction_axis before the >= 0 clamp, row 3c + axis:
+                         //     written by the forward so that the backward never re-reads the 192-byte SH block of a splat
     uint32_t* depth_bits; // [N] view depth as float bits (> 0.2, so they sort as integers): the scatter reads 4 B instead of a 64-B record
     uint8_t* flags;      // [N]
     uint32_t* block_sums;    // [ceil(N/256)]
@@ -115,6 +117,7 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     t.rec = c.take<float4>(4 * n);
     t.rect = c.take<ushort4>(n);
     t.touched = c.take<uint32_t>(n); t.offsets = c.take<uint32_t>(n); t.depth_bits = c.take<uint32_t>(n);
+    t.dcol_ddir = c.take<float>(9 * n);
     t.flags = c.take<uint8_t>(n);
     t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
     t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);

@@ -87,6 +87,34 @@ __device__ __forceinline__ void sh_basis(int deg, const float3 d, float B[16]) {
     }
 }
 
+// sum_k gk[k] * d basis_k / d(unit direction): with gk[k] = sh[k][c] this is d colour_c / d direction (forward), with
+// gk[k] = sh[k] . dL/dcolour it is dL/d direction (sr_sh_backward keeps its own copy for the multi-view rebuild).
+__device__ __forceinline__ float3 sh_dir_gradient(int deg, const float3 d, const float gk[16]) {
+    float3 dd_ = make_float3(0.f, 0.f, 0.f);
+    if (deg > 0) {
+        const float x = d.x, y = d.y, z = d.z;
+        dd_.x += -SH_C1 * gk[3]; dd_.y += -SH_C1 * gk[1]; dd_.z += SH_C1 * gk[2];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dd_.x += SH_C2_0 * y * gk[4] + SH_C2_2 * -2.f * x * gk[6] + SH_C2_3 * z * gk[7] + SH_C2_4 * 2.f * x * gk[8];
+            dd_.y += SH_C2_0 * x * gk[4] + SH_C2_1 * z * gk[5] + SH_C2_2 * -2.f * y * gk[6] + SH_C2_4 * -2.f * y * gk[8];
+            dd_.z += SH_C2_1 * y * gk[5] + SH_C2_2 * 4.f * z * gk[6] + SH_C2_3 * x * gk[7];
+            if (deg > 2) {
+                dd_.x += SH_C3_0 * 6.f * xy * gk[9] + SH_C3_1 * yz * gk[10] + SH_C3_2 * -2.f * xy * gk[11] +
+                         SH_C3_3 * -6.f * xz * gk[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * gk[13] +
+                         SH_C3_5 * 2.f * xz * gk[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * gk[15];
+                dd_.y += SH_C3_0 * (3.f * xx - 3.f * yy) * gk[9] + SH_C3_1 * xz * gk[10] +
+                         SH_C3_2 * (4.f * zz - xx - 3.f * yy) * gk[11] + SH_C3_3 * -6.f * yz * gk[12] +
+                         SH_C3_4 * -2.f * xy * gk[13] + SH_C3_5 * -2.f * yz * gk[14] + SH_C3_6 * -6.f * xy * gk[15];
+                dd_.z += SH_C3_1 * xy * gk[10] + SH_C3_2 * 8.f * yz * gk[11] +
+                         SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * gk[12] + SH_C3_4 * 8.f * xz * gk[13] +
+                         SH_C3_5 * (xx - yy) * gk[14];
+            }
+        }
+    }
+    return dd_;
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward preprocess
 // ------------------------------------------------------------------------------------------
@@ -204,6 +232,20 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         for (int k = 0; k < nb; ++k) {
                             rgb.x += B[k] * sh[3 * k]; rgb.y += B[k] * sh[3 * k + 1]; rgb.z += B[k] * sh[3 * k + 2];
                         }
+                        if (v.sh_degree > 0) {
+                            // d colour / d direction while the coefficients are at hand (36 bytes per splat instead of the
+                            // backward re-reading 192)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                float gk[16];
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) gk[k] = k < nb ? sh[3 * k + ch] : 0.f;
+                                const float3 j = sh_dir_gradient(v.sh_degree, d, gk);
+                                g.dcol_ddir[(size_t)(3 * ch) * s.N + idx] = j.x;
+                                g.dcol_ddir[(size_t)(3 * ch + 1) * s.N + idx] = j.y;
+                                g.dcol_ddir[(size_t)(3 * ch + 2) * s.N + idx] = j.z;
+                            }
+                        }
                         rgb.x += 0.5f; rgb.y += 0.5f; rgb.z += 0.5f;
                         if (rgb.x < 0.f) { flags |= kFlagClampR; rgb.x = 0.f; }
                         if (rgb.y < 0.f) { flags |= kFlagClampG; rgb.y = 0.f; }
@@ -290,8 +332,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = idx < s.N;
-    const bool stage_read = STAGE_SH && v.sh_degree >= 2;
-    // this splat's own loads are issued before the staged SH block so that everything is in flight together
     int radius_in = 0;
     uint32_t first_in = 0, cnt_in = 0;
     uint8_t flags_in = 0;
@@ -309,7 +349,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
         }
     }
-    // `reached` bytes of the first 4 instances are requested now, so their latency hides behind the SH staging below
+    // `reached` bytes of the first 4 instances are requested now, together with the splat's own loads
     // (most splats have <= 4 instances)
     const bool flags_on = use_reached_flags(g.total);
     uint32_t reached4 = 0x01010101u;
@@ -318,13 +358,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i)
             if (i < cnt_in) reached4 |= (uint32_t)reached[first_in + i] << (8 * i);
-    }
-    if constexpr (STAGE_SH) {
-        if (stage_read) {
-            const size_t first = (size_t)blockIdx.x * kBlock;
-            stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
-        }
-        __syncthreads();
     }
     // ---- segmented reduction of every splat's instance slots (fixed order -> deterministic) ----
     // Splats with many instances (large footprints; dense real scenes) are reduced by the whole wavefront, 64
@@ -519,35 +552,18 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
             float B[16];
             sh_basis(v.sh_degree, d, B);
-            const float* sh = stage_read ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4])
-                                         : s.shs + (size_t)idx * K * 3;
-            float gk[16];  // gk[k] = sh[k] . dL/dRGB
-            for (int k = 0; k < nb; ++k) {
-                const float c0 = sh[3 * k], c1 = sh[3 * k + 1], c2 = sh[3 * k + 2];  // read before the row is overwritten
-                gk[k] = c0 * dc.x + c1 * dc.y + c2 * dc.z;
-                if (!SH_TO_COLORS) { out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z; }
-            }
+            if (!SH_TO_COLORS)
+                for (int k = 0; k < nb; ++k) { out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z; }
             if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
-            float3 dd_ = make_float3(0.f, 0.f, 0.f);  // dL/d(unit direction)
             if (v.sh_degree > 0) {
-                const float x = d.x, y = d.y, z = d.z;
-                dd_.x += -SH_C1 * gk[3]; dd_.y += -SH_C1 * gk[1]; dd_.z += SH_C1 * gk[2];
-                if (v.sh_degree > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    dd_.x += SH_C2_0 * y * gk[4] + SH_C2_2 * -2.f * x * gk[6] + SH_C2_3 * z * gk[7] + SH_C2_4 * 2.f * x * gk[8];
-                    dd_.y += SH_C2_0 * x * gk[4] + SH_C2_1 * z * gk[5] + SH_C2_2 * -2.f * y * gk[6] + SH_C2_4 * -2.f * y * gk[8];
-                    dd_.z += SH_C2_1 * y * gk[5] + SH_C2_2 * 4.f * z * gk[6] + SH_C2_3 * x * gk[7];
-                    if (v.sh_degree > 2) {
-                        dd_.x += SH_C3_0 * 6.f * xy * gk[9] + SH_C3_1 * yz * gk[10] + SH_C3_2 * -2.f * xy * gk[11] +
-                                 SH_C3_3 * -6.f * xz * gk[12] + SH_C3_4 * (4.f * zz - 3.f * xx - yy) * gk[13] +
-                                 SH_C3_5 * 2.f * xz * gk[14] + SH_C3_6 * (3.f * xx - 3.f * yy) * gk[15];
-                        dd_.y += SH_C3_0 * (3.f * xx - 3.f * yy) * gk[9] + SH_C3_1 * xz * gk[10] +
-                                 SH_C3_2 * (4.f * zz - xx - 3.f * yy) * gk[11] + SH_C3_3 * -6.f * yz * gk[12] +
-                                 SH_C3_4 * -2.f * xy * gk[13] + SH_C3_5 * -2.f * yz * gk[14] + SH_C3_6 * -6.f * xy * gk[15];
-                        dd_.z += SH_C3_1 * xy * gk[10] + SH_C3_2 * 8.f * yz * gk[11] +
-                                 SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy) * gk[12] + SH_C3_4 * 8.f * xz * gk[13] +
-                                 SH_C3_5 * (xx - yy) * gk[14];
-                    }
+                // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
+                float3 dd_ = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float w = ch == 0 ? dc.x : (ch == 1 ? dc.y : dc.z);
+                    dd_.x += w * g.dcol_ddir[(size_t)(3 * ch) * s.N + idx];
+                    dd_.y += w * g.dcol_ddir[(size_t)(3 * ch + 1) * s.N + idx];
+                    dd_.z += w * g.dcol_ddir[(size_t)(3 * ch + 2) * s.N + idx];
                 }
                 // through the normalisation d = dv / |dv|
                 const float proj = dot3(d, dd_);
@@ -579,7 +595,7 @@ void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g,
     const int nb = (s.N + kBlock - 1) / kBlock;
     if (nb <= 0) return;
     const bool to_colors = s.shs && !gr.shs && gr.colors;
-    const bool stage = s.shs && v.sh_coeffs == 16 && (gr.shs || (to_colors && v.sh_degree >= 2));
+    const bool stage = s.shs && v.sh_coeffs == 16 && gr.shs;  // LDS rows only carry the SH gradient out (coalesced 16-byte stores)
     if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
     else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
     else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
