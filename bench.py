@@ -51,7 +51,8 @@ def stage_bytes(stage: str, n: int, vis: float, R: float, hw: int, c_in: int) ->
     """Algorithmic HBM bytes of one launch of a pipeline stage (SURVEY.md Appendix C terms)."""
     return {
         # read mean 12 + scale 12 + rot 16 + opacity 4 + colour input; write radii 4; visible: 40 B state
-        "preprocess": n * (44 + c_in + 4) + vis * 40,
+        # (+ 36 B colour/direction Jacobian on the SH path, which spares the backward the SH read)
+        "preprocess": n * (44 + c_in + 4) + vis * (40 + (36 if c_in > 12 else 0)),
         "scan": n / 256 * 8,
         # read depth/rect/count per splat, write one 8-byte key (depth bits, splat index) per instance
         "emit": n * 16 + R * 8,
@@ -62,8 +63,8 @@ def stage_bytes(stage: str, n: int, vis: float, R: float, hw: int, c_in: int) ->
         # read id 4 + first-instance offset 4 + 40 B state, write 40 B gradient moments per instance;
         # read dL/drgb 12, dL/ddepth 4, dL/dalpha 4, final_T 4, n_contrib 4 per pixel
         "render_backward": R * 88 + hw * 28,
-        # re-read inputs, read 40 B per instance, write all gradients
-        "preprocess_backward": n * (44 + c_in) + R * 40 + vis * 40 + n * (12 + 12 + 12 + 16 + 4 + c_in),
+        # re-read inputs (SH path: the 36 B Jacobian instead of the coefficients), read 40 B per instance, write all gradients
+        "preprocess_backward": n * (44 + (36 if c_in > 12 else c_in)) + R * 40 + vis * 40 + n * (12 + 12 + 12 + 16 + 4 + c_in),
     }[stage]
 
 
