@@ -55,12 +55,45 @@ def _f32c(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _as_input(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    """The tensor itself when the kernels can read it in place (fp32, contiguous, on `device`: the normal case, no
+    Python or GPU work), otherwise a converted copy."""
+    if t is None:
+        return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():
+        return t
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
 def _opt(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if (t is None or t.numel() == 0) else t
 
 
 class _ViewPack:
     """Keeps the contiguous camera tensors alive next to the C struct that points at them."""
+
+    _cache: "dict" = {}
+    _CACHE_MAX = 1024
+
+    @classmethod
+    def get(cls, rs: GaussianRasterizationSettings, device, sh_coeffs: int) -> "_ViewPack":
+        """Training renders the same cameras over and over (reference train.py:158-169), each time through a fresh
+        settings tuple that refers to the same camera tensors: the packed copy (four small strided-copy kernels and the
+        C struct) is kept per set of source tensors.  An entry holds its source tensors (so their ids cannot be
+        recycled) and is dropped when one of them was modified in place (`_version`)."""
+        src = (rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg)
+        key = (id(src[0]), id(src[1]), id(src[2]), id(src[3]), int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+               float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), bool(rs.prefiltered),
+               bool(rs.debug), device)
+        versions = (src[0]._version, src[1]._version, src[2]._version, src[3]._version)
+        hit = cls._cache.get(key)
+        if hit is not None and hit[1] == versions and all(a is b for a, b in zip(hit[2], src)):
+            return hit[0]
+        pack = cls(rs, device, sh_coeffs)
+        if len(cls._cache) >= cls._CACHE_MAX:
+            cls._cache.clear()
+        cls._cache[key] = (pack, versions, src)
+        return pack
 
     def __init__(self, rs: GaussianRasterizationSettings, device, sh_coeffs: int):
         self.viewmatrix = _f32c(rs.viewmatrix, device).reshape(-1)
@@ -101,7 +134,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         n = means3D.shape[0]
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
-        f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        f = lambda t: _as_input(t, dev)
         means3D_c, opac_c = f(means3D), f(opacities).reshape(-1)
         sh_c, col_c, sc_c, rot_c, cov_c = f(_opt(sh)), f(_opt(colors_precomp)), f(_opt(scales)), f(_opt(rotations)), f(_opt(cov3Ds_precomp))
         if opac_c.numel() != n:
@@ -114,11 +147,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("shs must have dimensions (num_points, K, 3)")
         sh_coeffs = 0 if sh_c is None else int(sh_c.shape[1])
 
-        view = _ViewPack(raster_settings, dev, sh_coeffs)
+        view = _ViewPack.get(raster_settings, dev, sh_coeffs)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.zeros(n, dtype=torch.int32, device=dev)
+        radii = torch.empty(n, dtype=torch.int32, device=dev)  # k_preprocess writes every element
         ctx.raster_settings = raster_settings
         ctx.color_grad_sink = color_grad_sink
         ctx.sh_coeffs = sh_coeffs
@@ -174,7 +207,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image = ctx.saved_tensors
         dev = means3D.device
         H, W = int(rs.image_height), int(rs.image_width)
-        g = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        g = lambda t: _as_input(t, dev)
         grad_color = g(grad_color)
         if grad_color is None:
             grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
