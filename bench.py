@@ -39,9 +39,13 @@ def parse():
     p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--cpu-baseline", choices=["auto", "none"], default="auto")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded baseline sample")
-    p.add_argument("--dp-mode", choices=["gather", "allreduce"], default="gather",
-                   help="N>1, SH path: 'gather' exchanges 12 B/splat colour gradients and rebuilds the SH gradient locally "
-                        "(splatfields_amd.view_parallel.sh_gather_step); 'allreduce' sum-all-reduces all five gradient tensors")
+    p.add_argument("--dp-mode", choices=["shard", "gather", "allreduce"], default="shard",
+                   help="N>1, SH path: 'shard' = SH coefficients sharded by splat range, colours and colour gradients travel by "
+                        "all-to-all (view_parallel.sh_sharded_step, ~98 B/splat on the wire); 'gather' = all-gather of 12 B/splat "
+                        "colour gradients, SH gradient rebuilt on every rank (sh_gather_step, ~161 B/splat); 'allreduce' = "
+                        "sum-all-reduce of all five gradient tensors (~413 B/splat).  A mode that fails on any rank falls back "
+                        "to the next one on all ranks.")
+    p.add_argument("--force-dp-path", action="store_true", help="run the chosen --dp-mode step function even with 1 GPU (overhead check)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing the control flow)")
     p.add_argument("--single-device", action="store_true", help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
     return p.parse_args()
@@ -94,7 +98,7 @@ def main():
     from splatfields_amd import _lib, rasterizer as rz
     from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-    from splatfields_amd.view_parallel import allreduce_gradients, sh_gather_step
+    from splatfields_amd.view_parallel import allreduce_gradients, sh_gather_step, sh_sharded_step
     import math
 
     lib = _lib.load()
@@ -109,8 +113,9 @@ def main():
     cams = [make_camera(k, W, H, device=dev) for k in range(8)]
     stats = {"R": 0.0, "vis": 0.0, "n": 0}
 
-    gather = world > 1 and use_sh and args.dp_mode == "gather"
-    state = {"gather": gather}
+    dp_active = (world > 1 or args.force_dp_path) and use_sh
+    modes = {"shard": ["shard", "gather", "allreduce"], "gather": ["gather", "allreduce"], "allreduce": ["allreduce"]}[args.dp_mode]
+    state = {"mode": modes[0] if dp_active else "allreduce"}
 
     def one_step_gather(step_idx: int, record: bool):
         step_cams = [cams[(step_idx * world + r) % len(cams)] for r in range(world)]
@@ -120,14 +125,17 @@ def main():
             seen["radii_vis"] = None
             torch.autograd.backward((color, depth, alpha), (gi / world, gd / world, ga / world))
 
-        sh_gather_step(params, step_cams, bg, args.sh_degree, bwd, rank=rank, world=world)
+        if state["mode"] == "shard":
+            sh_sharded_step(params, step_cams, bg, args.sh_degree, bwd, rank=rank, world=world)
+        else:
+            sh_gather_step(params, step_cams, bg, args.sh_degree, bwd, rank=rank, world=world)
         if record:
             stats["R"] += rz.LAST_INSTANCES
             stats["vis"] += float(N)
             stats["n"] += 1
 
     def one_step(step_idx: int, record: bool = False):
-        if state["gather"]:
+        if state["mode"] in ("shard", "gather"):
             return one_step_gather(step_idx, record)
         cam = cams[(step_idx * world + rank) % len(cams)]
         rs = GaussianRasterizationSettings(
@@ -158,18 +166,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if gather:
-        # make sure every rank can run the gather exchange; otherwise all ranks fall back to the plain all-reduce together
+    while dp_active and state["mode"] != "allreduce":
+        # make sure every rank can run this exchange; otherwise all ranks fall back to the next mode together
         ok = torch.ones(1, device=dev)
         try:
             one_step(0)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
-            print(f"[bench] rank {rank}: gather exchange failed ({e!r}); falling back to --dp-mode allreduce", file=sys.stderr)
+            print(f"[bench] rank {rank}: --dp-mode {state['mode']} failed ({e!r}); falling back", file=sys.stderr)
             ok.zero_()
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            state["gather"] = False
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() != 0:
+            break
+        state["mode"] = modes[modes.index(state["mode"]) + 1]
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -216,10 +226,12 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
                                f"1 view per GPU per step, colour+depth+alpha outputs, fwd+bwd"
-                               + ((", RCCL all-gather of colour gradients + all-reduce of the other per-splat gradients"
-                                   if state["gather"] else ", RCCL sum all-reduce of per-splat gradients") if world > 1 else ""),
+                               + ({"shard": ", SH coefficients sharded by splat range: RCCL all-to-all of colours and colour gradients "
+                                            "+ all-reduce of the other per-splat gradients",
+                                   "gather": ", RCCL all-gather of colour gradients + all-reduce of the other per-splat gradients",
+                                   "allreduce": ", RCCL sum all-reduce of per-splat gradients"}[state["mode"]] if world > 1 else ""),
                    "splats": N, "width": W, "height": H, "views_per_step": world,
-                   "visible_splats": vis, "tile_instances": R},
+                   "visible_splats": vis, "tile_instances": R, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": dom_bw / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                      "avg_launch_ms": stage_ms[dom]},

@@ -142,6 +142,12 @@ int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
 int sr_sh_forward(int n_splats, int sh_coeffs, int sh_degree, const float* means3D, const float* shs, const float* campos,
                   float* colors, unsigned char* clamped, void* hip_stream);
 
+/* sr_sh_forward for n_views cameras in one pass over the coefficients (SH-sharded view-parallel step):
+ * campos [n_views,3]; colors [n_views,N,3]; keep [n_views,N,3] (may be NULL) = 1 where the channel was not clamped, else 0
+ * (the factor that channel's colour gradient gets before sr_sh_backward). */
+int sr_sh_forward_views(int n_splats, int sh_coeffs, int sh_degree, int n_views, const float* means3D, const float* shs,
+                        const float* campos, float* colors, float* keep, void* hip_stream);
+
 /* Backward of sr_sh_forward for n_views cameras at once (view-parallel training).
  * campos [n_views,3]; dL_dcolors [n_views,N,3], zero where the colour was clamped in that view.
  * dL_dshs [N,K,3] (may be NULL) = scale * sum_v basis(dir_v) (x) dL_dcolors[v];

@@ -51,6 +51,7 @@ SYMBOLS = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrGrads),
                               C.c_void_p]),
     "sr_sh_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_sh_forward_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_sh_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sr_knn_workspace_bytes": (C.c_size_t, [C.c_int]),

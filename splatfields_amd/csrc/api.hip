@@ -255,6 +255,14 @@ int sr_sh_forward(int n, int sh_coeffs, int sh_degree, const float* means3D, con
     return check_hip(hipGetLastError(), "sh_forward");
 }
 
+int sr_sh_forward_views(int n, int sh_coeffs, int sh_degree, int n_views, const float* means3D, const float* shs, const float* campos,
+                        float* colors, float* keep, void* hip_stream) {
+    if (n < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail("bad arguments to sr_sh_forward_views");
+    if (n > 0 && n_views > 0 && (!means3D || !shs || !campos || !colors)) return fail("null pointer in sr_sh_forward_views");
+    sr::launch_sh_forward_views(n, sh_coeffs, sh_degree, n_views, means3D, shs, campos, colors, keep, static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "sh_forward_views");
+}
+
 int sr_sh_backward(int n, int sh_coeffs, int sh_degree, int n_views, const float* means3D, const float* shs, const float* campos,
                    const float* dL_dcolors, float scale, float* dL_dshs, float* dL_dmeans3D, int accumulate_means, void* hip_stream) {
     if (n < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail("bad arguments to sr_sh_backward");

@@ -41,6 +41,8 @@ void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream
 // sh.hip
 void launch_sh_forward(int N, int K, int deg, const float* means3D, const float* shs, const float* campos, float* colors,
                        unsigned char* clamped, hipStream_t st);
+void launch_sh_forward_views(int N, int K, int deg, int V, const float* means3D, const float* shs, const float* campos, float* colors,
+                             float* keep, hipStream_t st);
 void launch_sh_backward(int N, int K, int deg, int V, const float* means3D, const float* shs, const float* campos, const float* dcol,
                         float scale, float* d_shs, float* d_means, int accumulate_means, hipStream_t st);
 

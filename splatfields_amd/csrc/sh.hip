@@ -81,6 +81,39 @@ __global__ void __launch_bounds__(kBlock) k_sh_forward(int N, int K, int deg, co
     clamped[idx] = fl;
 }
 
+// The same evaluation for V cameras in one pass over the coefficients (the SH-sharded view-parallel step evaluates its
+// shard of the splats for every view of the step): colors [V][N][3]; keep [V][N][3] (may be NULL) = 1 where the channel was
+// not clamped, 0 where it was -- the factor its colour gradient gets in the backward.
+template <bool STAGE>
+__global__ void __launch_bounds__(kBlock) k_sh_forward_views(int N, int K, int deg, int V, const float* __restrict__ means3D,
+                                                             const float* __restrict__ shs, const float* __restrict__ campos,
+                                                             float* __restrict__ colors, float* __restrict__ keep) {
+    __shared__ float4 s_sh[STAGE ? kBlock * kShRowF4 : 1];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if constexpr (STAGE) {
+        const size_t first = (size_t)blockIdx.x * kBlock;
+        stage_sh_in(s_sh, shs, first, min(kBlock, N - (int)first));
+        __syncthreads();
+    }
+    if (idx >= N) return;
+    const float px = means3D[3 * (size_t)idx], py = means3D[3 * (size_t)idx + 1], pz = means3D[3 * (size_t)idx + 2];
+    const float* sh = STAGE ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4]) : shs + (size_t)idx * K * 3;
+    const int nb = (deg + 1) * (deg + 1);
+    for (int v = 0; v < V; ++v) {
+        float dx = px - campos[3 * v], dy = py - campos[3 * v + 1], dz = pz - campos[3 * v + 2];
+        const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= il; dy *= il; dz *= il;
+        float B[16];
+        sh_basis16(deg, dx, dy, dz, B);
+        float r = 0.f, g = 0.f, b = 0.f;
+        for (int k = 0; k < nb; ++k) { r += B[k] * sh[3 * k]; g += B[k] * sh[3 * k + 1]; b += B[k] * sh[3 * k + 2]; }
+        r += 0.5f; g += 0.5f; b += 0.5f;
+        const size_t o = ((size_t)v * N + idx) * 3;
+        if (keep) { keep[o] = r < 0.f ? 0.f : 1.f; keep[o + 1] = g < 0.f ? 0.f : 1.f; keep[o + 2] = b < 0.f ? 0.f : 1.f; }
+        colors[o] = fmaxf(r, 0.f); colors[o + 1] = fmaxf(g, 0.f); colors[o + 2] = fmaxf(b, 0.f);
+    }
+}
+
 // dcol: [V][N][3] colour gradients, ALREADY zeroed where the colour was clamped in that view.  campos: [V][3].
 // d_shs (may be NULL): [N][K][3] = scale * sum_v basis(dir_v) (x) dcol_v  (bands above `deg` get zeros).
 // d_means (may be NULL): [N][3] (+)= scale * sum_v d(colour_v . dcol_v)/d(mean)   (through the normalised direction).
@@ -153,6 +186,15 @@ void launch_sh_forward(int N, int K, int deg, const float* means3D, const float*
         hipLaunchKernelGGL(k_sh_forward<true>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, means3D, shs, campos, colors, clamped);
     else
         hipLaunchKernelGGL(k_sh_forward<false>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, means3D, shs, campos, colors, clamped);
+}
+
+void launch_sh_forward_views(int N, int K, int deg, int V, const float* means3D, const float* shs, const float* campos, float* colors,
+                             float* keep, hipStream_t st) {
+    if (N <= 0 || V <= 0) return;
+    if (K == 16)
+        hipLaunchKernelGGL(k_sh_forward_views<true>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, V, means3D, shs, campos, colors, keep);
+    else
+        hipLaunchKernelGGL(k_sh_forward_views<false>, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, K, deg, V, means3D, shs, campos, colors, keep);
 }
 
 void launch_sh_backward(int N, int K, int deg, int V, const float* means3D, const float* shs, const float* campos, const float* dcol,

@@ -39,6 +39,24 @@ def sh_forward(means3D: torch.Tensor, shs: torch.Tensor, campos: torch.Tensor, s
     return colors, clamped
 
 
+def sh_forward_views(means3D: torch.Tensor, shs: torch.Tensor, campos_views: torch.Tensor, sh_degree: int, want_keep: bool = True):
+    """Colours of the same splats for V cameras in one pass: -> (colors [V,N,3], keep [V,N,3] or None); ``keep`` is 1 where
+    a channel was not clamped to 0 and 0 where it was (multiply the colour gradient by it before ``sh_backward``)."""
+    lib = _lib.load()
+    if not means3D.is_cuda:
+        raise RuntimeError("sh_forward_views has no CPU path: tensors must be on a HIP ('cuda') device")
+    dev = means3D.device
+    m = means3D.detach().to(torch.float32).contiguous()
+    s = shs.detach().to(torch.float32).contiguous()
+    cp = campos_views.detach().to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
+    n, k, v = m.shape[0], s.shape[1], cp.shape[0]
+    colors = torch.empty(v, n, 3, dtype=torch.float32, device=dev)
+    keep = torch.empty(v, n, 3, dtype=torch.float32, device=dev) if want_keep else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_sh_forward_views(n, k, int(sh_degree), v, _p(m), _p(s), _p(cp), _p(colors), _p(keep), _stream(dev)))
+    return colors, keep
+
+
 def mask_clamped(dcolors: torch.Tensor, clamped: torch.Tensor) -> torch.Tensor:
     """Zeroes the colour gradient of channels that were clamped to 0 in the forward (as the rasterizer's backward does)."""
     bits = torch.tensor([1, 2, 4], dtype=torch.uint8, device=clamped.device)

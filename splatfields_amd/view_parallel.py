@@ -147,6 +147,120 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
         params["shs"].grad = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
 
 
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    """Equal-split all-to-all of contiguous buffers [world, ...].  RCCL moves device buffers directly; gloo (the CPU-backend
+    tests) only implements it for host tensors, so it is staged through the host there."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
+                    rank: int = None, world: int = None, group=None):
+    """View-parallel step with the SH coefficients SHARDED by splat range (ZeRO-style for the 192 B/splat tensor that is 80 %
+    of the parameters): rank r owns ``shs[lo:hi]``, r's slice of ``ceil(N / world)`` consecutive splats.
+
+    1. every rank evaluates the colours of ITS shard for ALL V views of the step (one pass over its coefficients,
+       ``sr_sh_forward_views``) and an all-to-all hands every rank the colours of all splats for the views it renders
+       (12 B/splat/view received instead of reading 192 B/splat of SH locally);
+    2. each rank rasterizes its views forward + backward on the precomputed-colour path (no SH traffic in the kernels);
+    3. a second all-to-all returns the colour gradients to the shard owners, which rebuild the SH gradient of their shard
+       from all views (``sr_sh_backward``) and add the view-direction term to their rows of ``means3D.grad``;
+    4. ONE packed all-reduce sums the geometric gradients (44 B/splat).
+
+    Wire traffic per rank: 2 x 10.5 + 77 = ~98 B/splat (plain all-reduce: ~413, `sh_gather_step`: ~161), and the per-rank
+    step is the cheaper precomputed-colour step.  Afterwards ``means3D / scales / rotations / opacities`` hold the full
+    gradient of the mean loss over all views on every rank (as after `sh_gather_step`); the SH gradient exists only for the
+    owned shard and is returned as ``(lo, hi, d_shs[hi - lo, K, 3])`` -- what a sharded optimizer consumes; ``shs.grad`` is
+    left ``None``.  ``params["shs"]`` may be the full tensor (only rows lo:hi are read) -- ``backward_fn`` as in
+    `sh_gather_step`."""
+    import math
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from . import sh as shmod
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    V = len(cams)
+    if V % world != 0:
+        raise ValueError("the number of views must be a multiple of the number of ranks")
+    k = V // world
+    names = ["means3D", "scales", "rotations", "opacities"]
+    for p in params.values():
+        p.grad = None
+    means3D, shs = params["means3D"], params["shs"]
+    dev = means3D.device
+    n = means3D.shape[0]
+    shard = (n + world - 1) // world
+    lo, hi = min(n, rank * shard), min(n, (rank + 1) * shard)
+    n_own = hi - lo
+    # views in (destination rank d, slot) order: rank d renders views d, d + world, ...
+    order = [d + sl * world for d in range(world) for sl in range(k)]
+    campos = torch.stack([cams[vi].camera_center.to(device=dev, dtype=torch.float32).reshape(3) for vi in order])
+    m_own, sh_own = means3D.detach()[lo:hi], shs.detach()[lo:hi]
+
+    # 1. colours of my shard for every view -> the ranks that render them
+    send = torch.zeros(world, k, shard, 3, dtype=torch.float32, device=dev) if n_own < shard else \
+        torch.empty(world, k, shard, 3, dtype=torch.float32, device=dev)
+    keep = None
+    if n_own > 0:
+        col_own, keep = shmod.sh_forward_views(m_own, sh_own, campos, sh_degree)     # [V, n_own, 3] each
+        send.view(V, shard, 3)[:, :n_own].copy_(col_own) if n_own < shard else send.view(V, shard, 3).copy_(col_own)
+    if world > 1:
+        recv = torch.empty_like(send)
+        _all_to_all(recv, send, group)
+    else:
+        recv = send
+    # recv[s, slot] = colours of shard s for my view `slot`
+
+    # 2. my views on the precomputed-colour path
+    dcol_send = torch.zeros(world, k, shard, 3, dtype=torch.float32, device=dev) if world * shard != n else \
+        torch.empty(world, k, shard, 3, dtype=torch.float32, device=dev)
+    for slot in range(k):
+        vi = rank + slot * world
+        cam = cams[vi]
+        cols = recv[:, slot].reshape(world * shard, 3)[:n].contiguous().requires_grad_(True)
+        rs = GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+            tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
+            colors_precomp=cols, scales=params["scales"], rotations=params["rotations"])
+        backward_fn(vi, color, depth, alpha)
+        g = cols.grad if cols.grad is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        dcol_send[:, slot].reshape(world * shard, 3)[:n].copy_(g) if k == 1 else \
+            dcol_send[:, slot].copy_(torch.nn.functional.pad(g, (0, 0, 0, world * shard - n)).view(world, shard, 3))
+    for name in names:
+        if params[name].grad is None:
+            params[name].grad = torch.zeros_like(params[name])
+
+    # 3. colour gradients back to the shard owners; SH gradient (and the view-direction term) of my shard from all views
+    if world > 1:
+        dcol_recv = torch.empty_like(dcol_send)
+        _all_to_all(dcol_recv, dcol_send, group)
+    else:
+        dcol_recv = dcol_send
+    d_shs = None
+    if n_own > 0:
+        dcol = dcol_recv.view(V, shard, 3)[:, :n_own] * keep                          # clamp mask of each view
+        d_means = torch.empty(n_own, 3, dtype=torch.float32, device=dev)
+        d_shs = shmod.sh_backward(m_own, sh_own, campos, dcol, sh_degree, want_shs=True, means_grad=d_means,
+                                  accumulate_means=False)
+        params["means3D"].grad[lo:hi] += d_means
+
+    # 4. the geometric gradients of all views
+    if world > 1:
+        flat, views = pack_gradients([params[name].grad for name in names])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        for name, v_ in zip(names, views):
+            params[name].grad = v_
+    return lo, hi, d_shs
+
+
 def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss: Callable, *, rank: int = None,
                        world: int = None, group=None) -> torch.Tensor:
     """One data-parallel step.  ``render_loss(view) -> scalar loss`` renders one view with the shared

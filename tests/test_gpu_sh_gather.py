@@ -70,10 +70,10 @@ def test_shs_path_equals_precomputed_colours_of_sh_stage(hip_device):
         assert torch.allclose(res[0][1][k], res[1][1][k], atol=2e-5 * scale), k
 
 
-def _reference_grads(dev):
+def _reference_grads(dev, n=N):
     """plain path: every view through the SH rasterizer, mean of the views, one backward (reference train.py:169-252)."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    sp = make_splats(N, seed=7, device=dev)
+    sp = make_splats(n, seed=7, device=dev)
     p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
     gi, gd, ga = make_upstream_grads(H, W, device=dev)
     for v in range(V):
@@ -135,3 +135,70 @@ def test_gather_step_two_ranks_equals_plain_multiview(hip_device):
         assert p.exitcode == 0
     for rank, g in outs:
         _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
+
+
+# ---- SH-sharded step: colours / colour gradients travel by all-to-all, each rank owns a slice of the SH tensor ----
+def _sharded_grads(dev, rank, world, n=N):
+    from splatfields_amd.view_parallel import sh_sharded_step
+    sp = make_splats(n, seed=7, device=dev)
+    p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    cams = [make_camera(v, W, H, device=dev) for v in range(V)]
+
+    def bwd(vi, c, d, a):
+        torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
+
+    lo, hi, d_shs = sh_sharded_step(p, cams, torch.ones(3, device=dev), DEG, bwd, rank=rank, world=world)
+    torch.cuda.synchronize()
+    assert p["shs"].grad is None
+    out = {k: p[k].grad.detach().cpu() for k in NAMES if k != "shs"}
+    return out, (lo, hi, None if d_shs is None else d_shs.detach().cpu())
+
+
+def _close_sharded(out, shard, ref):
+    for k in NAMES:
+        if k == "shs":
+            continue
+        scale = ref[k].abs().max().item()
+        assert torch.allclose(out[k], ref[k], atol=5e-5 * scale), (k, (out[k] - ref[k]).abs().max().item() / scale)
+    lo, hi, d_shs = shard
+    if hi > lo:
+        scale = ref["shs"].abs().max().item()
+        assert torch.allclose(d_shs, ref["shs"][lo:hi], atol=5e-5 * scale), (d_shs - ref["shs"][lo:hi]).abs().max().item() / scale
+
+
+def test_sharded_step_single_rank_equals_plain_multiview(hip_device):
+    out, shard = _sharded_grads(hip_device, 0, 1)
+    assert shard[0] == 0 and shard[1] == N
+    _close_sharded(out, shard, _reference_grads(hip_device))
+
+
+def _worker_sharded(rank, world, port, q, n):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")  # both ranks share the single GPU of the test box; gloo moves the tensors
+    torch.cuda.set_device(dev)
+    out, (lo, hi, d_shs) = _sharded_grads(dev, rank, world, n)
+    q.put((rank, {k: v.numpy().copy() for k, v in out.items()}, lo, hi, None if d_shs is None else d_shs.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [N, N - 1])   # N - 1 is odd: the last shard is one row short (padding path)
+def test_sharded_step_two_ranks_equals_plain_multiview(hip_device, n):
+    ref = _reference_grads(hip_device, n)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q, n)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    covered = 0
+    for rank, g, lo, hi, d_shs in outs:
+        _close_sharded({k: torch.from_numpy(v) for k, v in g.items()}, (lo, hi, None if d_shs is None else torch.from_numpy(d_shs)), ref)
+        covered += hi - lo
+    assert covered == n   # the shards tile the splats
