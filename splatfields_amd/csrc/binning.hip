@@ -1,16 +1,17 @@
 // Per-tile bucketing and sort for gfx950 (replaces the published pipeline's
 // InclusiveSum -> duplicateWithKeys -> 64-bit global radix sort -> identifyTileRanges).
 //
-// MI355X-first design: the sort key is (tile, depth, instance).
+// MI355X-first design: the sort key is (tile, depth, splat index).
 //  * The tile digit is resolved by a bucket scatter.  Per-tile counts come from a count matrix [chunk][tile] built with
-//    LDS histograms (no global atomics), prefix-summed along chunks and tiles, which also yields the tile ranges.
+//    LDS histograms (no global atomics), prefix-summed along chunks and tiles, which also yields the tile ranges (and the
+//    longest-list-first launch order of the per-tile kernels).
 //  * Each tile's list -- ~900 entries at 1 M splats / 800x800, thousands in dense scenes -- is sorted by one workgroup on
-//    the 64-bit key (depth bits << 32 | instance index): a bitonic network held in registers (lane exchanges by DPP /
-//    v_permlane swaps, 3 LDS stages) for runs of <= 1024 entries, and a multi-way rank merge in LDS for longer lists.
-//    Instance indices grow with the splat index, so the order is exactly the published "stable sort by depth, ties by
-//    splat index", and it is a total order: the result does not depend on the arrival order of the scatter
-//    (bit-reproducible).
-// HBM traffic per instance: 16 B scatter write + 16 B sort read + 8 B sorted write, versus 6 radix passes x 24 B for a
+//    the 64-bit key (depth bits << 32 | splat index), whose low half is also the payload: a key-only bitonic network held
+//    in registers (lane exchanges by DPP / v_permlane swaps, 3 LDS stages) for runs of <= 1024 entries, and a multi-way
+//    rank merge in LDS for longer lists.  A splat appears once per tile, so the key is unique and the order is exactly
+//    the published "stable sort by depth, ties by splat index": a total order, independent of the arrival order of the
+//    scatter (bit-reproducible).
+// HBM traffic per instance: 8 B scatter write + 8 B sort read + 4 B sorted write, versus 6 radix passes x 24 B for a
 // global 44-bit LSD sort.
 #include "kernels.h"
 #include "expand.h"

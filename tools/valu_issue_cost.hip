@@ -10,10 +10,15 @@ __global__ void __launch_bounds__(256) k(float* out, int n) {
     float a0 = threadIdx.x * 0.001f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float b = 1.0001f, c = 0.5f;
     unsigned long long m = 0;
+    // KIND 12..15: the v_fma stream under a partial EXEC mask (does the SIMD skip passes whose lanes are all disabled?)
+    if (KIND == 12) asm volatile("s_mov_b32 exec_lo, -1\n s_mov_b32 exec_hi, 0");
+    if (KIND == 13) asm volatile("s_mov_b32 exec_lo, 0xffff\n s_mov_b32 exec_hi, 0");
+    if (KIND == 14) asm volatile("s_mov_b32 exec_lo, 0xffff\n s_mov_b32 exec_hi, 0xffff");
+    if (KIND == 15) asm volatile("s_mov_b32 exec_lo, 0xff\n s_mov_b32 exec_hi, 0");
     for (int it = 0; it < n; ++it) {
 #pragma unroll
         for (int r = 0; r < REP / 8; ++r) {
-            if (KIND == 0) { asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
+            if (KIND == 0 || KIND >= 12) { asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); }
             if (KIND == 1) { asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b)); }
             if (KIND == 2) { asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (KIND == 3) { asm volatile("v_cmp_lt_f32 %8, %0, %1\n v_cmp_lt_f32 %8, %1, %2\n v_cmp_lt_f32 %8, %2, %3\n v_cmp_lt_f32 %8, %3, %4\n v_cmp_lt_f32 %8, %4, %5\n v_cmp_lt_f32 %8, %5, %6\n v_cmp_lt_f32 %8, %6, %7\n v_cmp_lt_f32 %8, %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(m)); }
@@ -27,6 +32,7 @@ __global__ void __launch_bounds__(256) k(float* out, int n) {
             if (KIND == 11) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc"); }
         }
     }
+    if (KIND >= 12) asm volatile("s_mov_b64 exec, -1");
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)m;
 }
 template <int KIND> double run(float* d, const char* name) {
@@ -46,5 +52,6 @@ int main() {
     run<0>(d, "v_fma_f32"); run<1>(d, "v_mul_f32"); run<2>(d, "v_exp_f32"); run<3>(d, "v_cmp_lt_f32 -> sgpr"); run<11>(d, "v_cmp_lt_f32 -> vcc");
     run<4>(d, "v_cndmask_b32 (sgpr)"); run<5>(d, "v_add_f32_dpp"); run<6>(d, "v_permlane32_swap"); run<7>(d, "v_pk_fma_f32"); run<8>(d, "v_rcp_f32");
     run<9>(d, "v_mov_b32"); run<10>(d, "ds_bpermute_b32");
+    run<12>(d, "v_fma exec=lanes 0-31"); run<13>(d, "v_fma exec=lanes 0-15"); run<14>(d, "v_fma exec=rows 0,2"); run<15>(d, "v_fma exec=lanes 0-7");
     return 0;
 }
