@@ -105,11 +105,16 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
             if (!tiles) v = g.block_sums[i];
             else if (!use_matrix) v = g.tile_count[i];
             else {
-                for (int sg = 0; sg < ch.segments; ++sg) {
-                    const size_t at = (size_t)sg * ch.tiles_padded + i;
-                    const uint32_t x = g.segtot[at];
-                    g.segbase[at] = v;
-                    v += x;
+                // all segment totals of the tile are requested before the first dependent store (interleaved they were
+                // one memory round trip per segment: the stores may alias the loads as far as the compiler knows)
+                constexpr int kMaxSeg = (kMaxChunks + kSegRows - 1) / kSegRows;
+                uint32_t x[kMaxSeg];
+#pragma unroll
+                for (int sg = 0; sg < kMaxSeg; ++sg) x[sg] = sg < ch.segments ? g.segtot[(size_t)sg * ch.tiles_padded + i] : 0u;
+#pragma unroll
+                for (int sg = 0; sg < kMaxSeg; ++sg) {
+                    if (sg < ch.segments) g.segbase[(size_t)sg * ch.tiles_padded + i] = v;
+                    v += x[sg];
                 }
             }
         }
