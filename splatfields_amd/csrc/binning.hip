@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
 }
 
 // Exclusive prefix along the chunk axis, per tile column, inside one segment of kSegRows chunks.
-// grid = (tiles_padded / 64, segments); the 128 x 64 sub-matrix is transposed through LDS so both the
+// grid = (tiles_padded / 64, segments); the kSegRows x 64 sub-matrix is transposed through LDS so both the
 // loads and the stores are row-contiguous.
 __global__ void __launch_bounds__(kBlock) k_colscan_local(const Geom g, const Chunking ch) {
     __shared__ uint32_t s_m[kSegRows][65];
@@ -65,12 +65,13 @@ __global__ void __launch_bounds__(kBlock) k_colscan_local(const Geom g, const Ch
     __syncthreads();
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     uint32_t run = 0;
-    for (int r = part * 32; r < part * 32 + 32; ++r) { const uint32_t x = s_m[r][c]; s_m[r][c] = run; run += x; }
+    constexpr int kPartRows = kSegRows / 4;
+    for (int r = part * kPartRows; r < (part + 1) * kPartRows; ++r) { const uint32_t x = s_m[r][c]; s_m[r][c] = run; run += x; }
     s_part[part][c] = run;
     __syncthreads();
     uint32_t base = 0;
     for (int p2 = 0; p2 < part; ++p2) base += s_part[p2][c];
-    for (int r = part * 32; r < part * 32 + 32; ++r) s_m[r][c] += base;
+    for (int r = part * kPartRows; r < (part + 1) * kPartRows; ++r) s_m[r][c] += base;
     if (part == 3) g.segtot[(size_t)blockIdx.y * ch.tiles_padded + col0 + c] = base + run;
     __syncthreads();
     for (int i = threadIdx.x; i < kSegRows * 64; i += kBlock) {

@@ -63,7 +63,10 @@ struct Geom {
 #define SR_MAX_CHUNKS 1024
 #endif
 constexpr int kMaxChunks = SR_MAX_CHUNKS;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
-constexpr int kSegRows = 128;           // chunks per column-scan segment
+#ifndef SR_SEG_ROWS
+#define SR_SEG_ROWS 128
+#endif
+constexpr int kSegRows = SR_SEG_ROWS;   // chunks per column-scan segment
 constexpr int kMaxMatrixTiles = 16384;  // LDS histogram of 64 KiB; larger images use the global-atomic fallback
 
 struct Chunking { int n_sub, chunks, sub_per_chunk, segments, tiles_padded; };
