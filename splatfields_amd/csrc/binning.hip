@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         const uint32_t first_splat = (uint32_t)sb * kBlock;
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t i) {
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t) {
             uint32_t slot;
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);

@@ -230,10 +230,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return wave_base + inc - v;
 }
 
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    const int lane = lane_id();
-    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
-}
 
 // The alpha of one (pixel, splat) pair -- the same instruction sequence in forward and backward, so both make the same
 // skip decision (alpha < 1/255).  The per-splat record holds the exponent in completed-square form, in log2 units:

@@ -182,7 +182,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
             const float det = a * c - b * b;
             if (det != 0.0f) {
                 const float det_inv = 1.0f / det;
-                const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
                 const float mid = 0.5f * (a + c);
                 const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
                 const float my_radius = ceilf(3.0f * sqrtf(lam));

@@ -75,7 +75,6 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     const bool inside = px < v.W && py < v.H;
     const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
-    const uint64_t lt = lanemask_lt();
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
     // Pixels still accumulating (not yet stopped by T < 1e-4) are tracked as a SCALAR 64-bit mask: all the skip / stop /
@@ -185,7 +184,6 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
     const int n = (int)(end - start);
-    const uint64_t lt = lanemask_lt();
     const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
 
     int my_last = 0;
