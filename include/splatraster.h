@@ -21,6 +21,9 @@
  *   sr_mark_visible
  *        <- [EXT] `_C.mark_visible(...)` (`GaussianRasterizer.markVisible`; never called by
  *           SplatFields, exported for completeness).
+ *   sr_densification_stats
+ *        <- reference train.py:280-286 and scene/gaussian_model.py:427-438 (`add_densification_stats`): the
+ *           consumers of `radii` and `viewspace_points.grad`, fused into one kernel.
  *   SrView
  *        <- the 12-field `GaussianRasterizationSettings` built at reference
  *           gaussian_renderer/__init__.py:59-72 (and :76-89 for the alpha pass).
@@ -135,6 +138,14 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
 /* present[i] = 1 iff splat i passes the near-plane test (view z > 0.2). */
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, unsigned char* present, void* hip_stream);
+
+/* The per-view densification bookkeeping that consumes the rasterizer's outputs (reference train.py:280-286 and
+ * scene/gaussian_model.py:427-438, `add_densification_stats`), for the splats with radii > 0 (`visibility_filter`), fused:
+ *   grad_accum[i] += |dL_dmeans2D[i, :2]|;   denom[i] += 1;   max_radii2D[i] = max(max_radii2D[i], radii[i]).
+ * The reference does this with boolean-mask indexing (several kernels and a host synchronisation per iteration).
+ * Any of the three outputs may be NULL. */
+int sr_densification_stats(int n_splats, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom,
+                           float* max_radii2D, void* hip_stream);
 
 /* SH colour evaluation as a stand-alone stage (the SH part of the forward preprocess; reference utils/sh_utils.py:57-112,
  * extract_geo.py:40-44): colors[N,3] = max(sum_k basis_k(dir) shs[k] + 0.5, 0), clamped[N] bit c set where channel c was

@@ -60,6 +60,7 @@ SYMBOLS = {
     "sr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "sr_profile_stage_name": (C.c_char_p, [C.c_int]),
     "sr_mark_visible": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_densification_stats": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 PROFILE_STAGES = 7

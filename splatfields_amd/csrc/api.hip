@@ -247,6 +247,14 @@ int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const 
     return check_hip(hipGetLastError(), "mark_visible");
 }
 
+int sr_densification_stats(int n, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii2D,
+                           void* hip_stream) {
+    if (n < 0) return fail("bad arguments to sr_densification_stats");
+    if (n > 0 && (!dL_dmeans2D || !radii)) return fail("null pointer in sr_densification_stats");
+    sr::launch_densification_stats(n, dL_dmeans2D, radii, grad_accum, denom, max_radii2D, static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "densification_stats");
+}
+
 int sr_sh_forward(int n, int sh_coeffs, int sh_degree, const float* means3D, const float* shs, const float* campos,
                   float* colors, unsigned char* clamped, void* hip_stream) {
     if (n < 0 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) return fail("bad arguments to sr_sh_forward");

@@ -18,6 +18,8 @@ struct GradsK {
 // preprocess.hip
 void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* radii, hipStream_t st);
 void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t st);
+void launch_densification_stats(int N, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii2D,
+                                hipStream_t st);
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
                                 const float* slots, const uint8_t* reached, const GradsK& gr, hipStream_t st);
 // binning.hip

@@ -312,6 +312,26 @@ __global__ void k_mark_visible(int N, const float* __restrict__ means3D, const f
     present[idx] = z > kNearCullZ ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Densification statistics of one rendered view (the consumers of the rasterizer's means2D gradient and radii)
+// ------------------------------------------------------------------------------------------
+__global__ void k_densification_stats(int N, const float* __restrict__ dL_dmeans2D, const int* __restrict__ radii,
+                                      float* __restrict__ grad_accum, float* __restrict__ denom, float* __restrict__ max_radii2D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N) return;
+    const int r = radii[idx];
+    if (r <= 0) return;  // visibility_filter = radii > 0
+    const float gx = dL_dmeans2D[3 * (size_t)idx], gy = dL_dmeans2D[3 * (size_t)idx + 1];
+    if (grad_accum) grad_accum[idx] += sqrtf(gx * gx + gy * gy);
+    if (denom) denom[idx] += 1.0f;
+    if (max_radii2D) max_radii2D[idx] = fmaxf(max_radii2D[idx], (float)r);
+}
+
+void launch_densification_stats(int N, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii2D,
+                                hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(k_densification_stats, dim3((N + 255) / 256), dim3(256), 0, st, N, dL_dmeans2D, radii, grad_accum, denom, max_radii2D);
+}
+
 void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t st) {
     if (N <= 0) return;
     hipLaunchKernelGGL(k_mark_visible, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, st, N, means3D, viewmatrix, present);

@@ -117,3 +117,29 @@ def test_sh_storage_widths(hip_device, K, deg):
     assert (gr["shs"][:, (deg + 1) ** 2:] == 0).all()  # inactive bands get exact zeros
     assert grad_error(gr["shs"][:, : (deg + 1) ** 2], gref["shs"]) < 5e-3
     assert grad_error(gr["means3D"], gref["means3D"]) < 5e-3
+
+
+def test_fused_densification_stats_equal_the_reference_updates(hip_device):
+    """reference train.py:280-286 + scene/gaussian_model.py:427-431 restated with the boolean-mask indexing they use."""
+    from splatfields_amd.densify_stats import densification_stats
+    n = 50000
+    gen = torch.Generator().manual_seed(5)
+    grad = torch.randn(n, 3, generator=gen).to(hip_device)
+    radii = torch.randint(-1, 40, (n,), generator=gen, dtype=torch.int32).clamp_min(0).to(hip_device)
+    accum0 = torch.rand(n, 1, generator=gen).to(hip_device)
+    denom0 = torch.randint(0, 5, (n, 1), generator=gen).float().to(hip_device)
+    maxr0 = (torch.rand(n, generator=gen) * 30).to(hip_device)
+    # reference formulation
+    vis = radii > 0
+    accum_ref, denom_ref, maxr_ref = accum0.clone(), denom0.clone(), maxr0.clone()
+    maxr_ref[vis] = torch.max(maxr_ref[vis], radii[vis].float())
+    accum_ref[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)
+    denom_ref[vis] += 1
+    accum, denom, maxr = accum0.clone(), denom0.clone(), maxr0.clone()
+    densification_stats(grad, radii, accum, denom, maxr)
+    torch.cuda.synchronize()
+    assert torch.allclose(accum, accum_ref, rtol=1e-6, atol=1e-7)
+    assert torch.equal(denom, denom_ref) and torch.equal(maxr, maxr_ref)
+    # optional outputs
+    densification_stats(grad, radii, None, None, maxr)
+    assert torch.equal(maxr, maxr_ref)
