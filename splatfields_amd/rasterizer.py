@@ -43,6 +43,7 @@ LAST_INSTANCES = 0  # tile-splat instances of the most recent forward (diagnosti
 # Per-device estimate of the instance count used to size the binning buffer BEFORE the count is known, so that
 # the forward never drains the GPU pipeline (include/splatraster.h: sr_forward).  Grows on demand.
 _CAPACITY = {}
+_INSTANCES_PER_SPLAT = {}
 _CAPACITY_HEADROOM = 1.25
 
 
@@ -175,7 +176,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             image = torch.empty(lib.sr_image_bytes(H, W), dtype=torch.uint8, device=dev)
             inst = C.c_longlong(0)
             key = (dev.index, n, H, W)
-            capacity = _CAPACITY.get(key) or max(4 * n, 1 << 16)
+            # known size: what it needed before; new size (the cloud was densified / pruned): the instances-per-splat ratio
+            # this image size has shown so far, so that the first forward after a densification step does not fall into the
+            # re-run path
+            ratio = _INSTANCES_PER_SPLAT.get((dev.index, H, W))
+            capacity = _CAPACITY.get(key) or (max(4 * n, 1 << 16) if ratio is None
+                                              else int(ratio * n * _CAPACITY_HEADROOM) + 1024)
             binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
             status = lib.sr_forward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
                                     capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), C.byref(inst), stream)
@@ -189,6 +195,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             else:
                 _lib.check(status)
             _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(instances * _CAPACITY_HEADROOM) + 1024)
+            if len(_CAPACITY) > 4096:  # a long training run changes the splat count thousands of times
+                _CAPACITY.clear()
+            rkey = (dev.index, H, W)
+            _INSTANCES_PER_SPLAT[rkey] = max(_INSTANCES_PER_SPLAT.get(rkey, 0.0), instances / max(n, 1))
         global LAST_INSTANCES
         LAST_INSTANCES = instances
         ctx.instances = instances
