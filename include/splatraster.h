@@ -74,7 +74,14 @@ typedef struct SrSplats {
     const float* cov3D_precomp;  /* device [N,6] (xx,xy,xz,yy,yz,zz) or NULL */
     const float* shs;            /* device [N,K,3] or NULL */
     const float* colors_precomp; /* device [N,3] or NULL (exactly one of shs / colors_precomp) */
+    int raw_params;              /* bit mask of SR_RAW_*: inputs that arrive as the optimiser's raw parameters; the activation of
+                                  * reference scene/gaussian_model.py:64-86 is applied inside the preprocess kernels and its
+                                  * derivative inside sr_backward (the gradients are then w.r.t. the raw parameters) */
 } SrSplats;
+
+#define SR_RAW_SCALES 1    /* scales = log-scales:        get_scaling  = exp(_scaling)          (gaussian_model.py:64-68) */
+#define SR_RAW_OPACITY 2   /* opacities = logits:         get_opacity  = sigmoid(_opacity)      (gaussian_model.py:84-86) */
+#define SR_RAW_ROTATIONS 4 /* rotations = unnormalised:   get_rotation = normalize(_rotation)   (gaussian_model.py:70-72) */
 
 /* Dense per-splat gradient outputs, all written in full by sr_backward (culled splats get zeros). */
 typedef struct SrGrads {

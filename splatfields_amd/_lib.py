@@ -24,7 +24,7 @@ class SrView(C.Structure):
 class SrSplats(C.Structure):
     _fields_ = [("count", C.c_int), ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs", C.c_void_p),
-                ("colors_precomp", C.c_void_p)]
+                ("colors_precomp", C.c_void_p), ("raw_params", C.c_int)]
 
 
 class SrGrads(C.Structure):
@@ -65,6 +65,7 @@ SYMBOLS = {
 
 PROFILE_STAGES = 7
 SR_NEED_CAPACITY = 2
+SR_RAW_SCALES, SR_RAW_OPACITY, SR_RAW_ROTATIONS = 1, 2, 4
 _lib = None
 
 

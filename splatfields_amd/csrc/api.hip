@@ -94,6 +94,7 @@ sr::SplatsK make_splats(const SrSplats* s) {
     sr::SplatsK k;
     k.N = s->count; k.means3D = s->means3D; k.opacities = s->opacities; k.scales = s->scales;
     k.rotations = s->rotations; k.cov3D = s->cov3D_precomp; k.shs = s->shs; k.colors = s->colors_precomp;
+    k.raw = s->raw_params;
     return k;
 }
 

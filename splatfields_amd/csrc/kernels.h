@@ -8,6 +8,7 @@ struct SplatsK {
     int N;
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* cov3D; const float* shs; const float* colors;
+    int raw;  // SR_RAW_* bits: activations applied on load, their derivatives on the way out
 };
 
 struct GradsK {

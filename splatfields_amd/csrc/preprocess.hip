@@ -115,6 +115,19 @@ __device__ __forceinline__ float3 sh_dir_gradient(int deg, const float3 d, const
     return dd_;
 }
 
+// The optimiser's raw parameters -> what the rasterizer consumes (reference scene/gaussian_model.py:64-86), applied on load
+// in both preprocess kernels when the SR_RAW_* bit is set.  `q_norm` returns |q| of the raw quaternion (1 if not raw).
+__device__ __forceinline__ void activate_inputs(int raw, float3& sc, float& opac, float4& q, float& q_norm) {
+    if (raw & SR_RAW_SCALES) sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+    if (raw & SR_RAW_OPACITY) opac = 1.0f / (1.0f + expf(-opac));
+    q_norm = 1.0f;
+    if (raw & SR_RAW_ROTATIONS) {
+        q_norm = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);  // F.normalize's eps
+        const float inv = 1.0f / q_norm;
+        q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward preprocess
 // ------------------------------------------------------------------------------------------
@@ -148,6 +161,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
         __syncthreads();
     }
+    if (s.raw) { float qn; activate_inputs(s.raw, sc_in, opac_in, q_in, qn); }
 
     if (idx < s.N) {
         int out_radius = 0;
@@ -368,6 +382,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
         }
     }
+    float q_norm = 1.0f;
+    if (s.raw) activate_inputs(s.raw, sc_in, opac_in, q_in, q_norm);
     // `reached` bytes of the first 4 instances are requested now, together with the splat's own loads
     // (most splats have <= 4 instances)
     const bool flags_on = use_reached_flags(g.total);
@@ -592,6 +608,16 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             }
         }
         if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+    }
+    if (s.raw) {  // derivatives of the activations: gradients w.r.t. the raw parameters
+        if (s.raw & SR_RAW_SCALES) { d_scale.x *= sc_in.x; d_scale.y *= sc_in.y; d_scale.z *= sc_in.z; }   // d exp = exp
+        if (s.raw & SR_RAW_OPACITY) d_opac *= opac_in * (1.0f - opac_in);                                   // d sigmoid
+        if (s.raw & SR_RAW_ROTATIONS) {                                                                     // d (q / |q|)
+            const float dot = q_in.x * d_rot.x + q_in.y * d_rot.y + q_in.z * d_rot.z + q_in.w * d_rot.w;
+            const float inv = 1.0f / q_norm;
+            d_rot = make_float4((d_rot.x - q_in.x * dot) * inv, (d_rot.y - q_in.y * dot) * inv, (d_rot.z - q_in.z * dot) * inv,
+                                (d_rot.w - q_in.w * dot) * inv);
+        }
     }
     if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
 

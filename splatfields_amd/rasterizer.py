@@ -112,9 +112,9 @@ class _ViewPack:
             self.campos.data_ptr(), self.bg.data_ptr())
 
 
-def _splats_struct(n, means3D, opacities, scales, rotations, cov3D, shs, colors) -> _lib.SrSplats:
+def _splats_struct(n, means3D, opacities, scales, rotations, cov3D, shs, colors, raw_params: int = 0) -> _lib.SrSplats:
     g = lambda t: None if t is None else t.data_ptr()
-    return _lib.SrSplats(int(n), g(means3D), g(opacities), g(scales), g(rotations), g(cov3D), g(shs), g(colors))
+    return _lib.SrSplats(int(n), g(means3D), g(opacities), g(scales), g(rotations), g(cov3D), g(shs), g(colors), int(raw_params))
 
 
 def _stream_ptr(device) -> C.c_void_p:
@@ -126,7 +126,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, color_grad_sink=None):
+                raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -155,6 +155,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(n, dtype=torch.int32, device=dev)  # k_preprocess writes every element
         ctx.raster_settings = raster_settings
         ctx.color_grad_sink = color_grad_sink
+        ctx.raw_params = int(raw_params)
         ctx.sh_coeffs = sh_coeffs
         ctx.n = n
         ctx.opac_shape = tuple(opacities.shape)
@@ -171,7 +172,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
-            splats = _splats_struct(n, means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c)
+            splats = _splats_struct(n, means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, raw_params)
             geom = torch.empty(lib.sr_geom_bytes(n, H, W), dtype=torch.uint8, device=dev)
             image = torch.empty(lib.sr_image_bytes(H, W), dtype=torch.uint8, device=dev)
             inst = C.c_longlong(0)
@@ -212,7 +213,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         n = ctx.n
         if n == 0:
-            return (None,) * 10
+            return (None,) * 11
         lib = _lib.load()
         means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image = ctx.saved_tensors
         dev = means3D.device
@@ -233,7 +234,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         d_col = new(n, 3) if (col is not None or sink is not None) else None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
-            splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col)
+            splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col, ctx.raw_params)
             scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.capacity), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col))
@@ -247,16 +248,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = [d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov]
         # the kernels compute in fp32; hand each gradient back in its input's dtype (fp64 / fp16 callers)
         grads = [g_ if (g_ is None or dt is None or g_.dtype == dt) else g_.to(dt) for g_, dt in zip(grads, ctx.in_dtypes)]
-        return (*grads, None, None)
+        return (*grads, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, color_grad_sink=None):
+                        raster_settings, color_grad_sink=None, raw_params: int = 0):
     """Returns (color, radii, depth, alpha).  ``alpha`` (= 1 - final transmittance) is the fused equivalent of
     the reference's second rasterization with white colours on a black background
     (gaussian_renderer/__init__.py:104-115)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, color_grad_sink)
+                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params)
 
 
 class GaussianRasterizer(nn.Module):
@@ -296,6 +297,18 @@ class GaussianRasterizer(nn.Module):
         self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings, color_grad_sink)
+
+    def forward_raw(self, means3D, means2D, opacity_logits, shs=None, colors_precomp=None, log_scales=None, quaternions=None,
+                    color_grad_sink=None):
+        """``forward_ex`` on the optimiser's RAW parameters: ``_opacity`` (logits), ``_scaling`` (log-scales, [N,3]) and
+        ``_rotation`` (unnormalised quaternions) as ``GaussianModel`` stores them (reference scene/gaussian_model.py:64-86).
+        ``sigmoid`` / ``exp`` / ``normalize`` run inside the preprocess kernels and their derivatives inside the backward,
+        so the six element-wise kernels (and their six backward kernels) the accessors launch per iteration disappear; the
+        gradients returned are w.r.t. the raw parameters.  Returns (color, radii, depth, alpha)."""
+        self._check(shs, colors_precomp, log_scales, quaternions, None)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacity_logits, log_scales, quaternions, None,
+                                   self.raster_settings, color_grad_sink,
+                                   _lib.SR_RAW_SCALES | _lib.SR_RAW_OPACITY | _lib.SR_RAW_ROTATIONS)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):

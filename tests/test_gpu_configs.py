@@ -2,6 +2,8 @@
 configs[3] = configs[1] sharded over 8 GPUs, covered by the gloo test + bench.py --gpus N).
 At these sizes the torch oracle is too slow for whole images, so every view is compared with the C oracle
 (same fp32 decisions, explicit backward) on images AND full gradients -- the C oracle handles 300 k splats in seconds."""
+import math
+
 import pytest
 import torch
 
@@ -143,3 +145,47 @@ def test_fused_densification_stats_equal_the_reference_updates(hip_device):
     # optional outputs
     densification_stats(grad, radii, None, None, maxr)
     assert torch.equal(maxr, maxr_ref)
+
+
+def test_raw_parameter_path_equals_activations_in_torch(hip_device):
+    """forward_raw on (logits, log-scales, unnormalised quaternions) == forward_ex on (sigmoid, exp, normalize) of them
+    (reference scene/gaussian_model.py:64-86), outputs and gradients w.r.t. the RAW parameters."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    n, W, H = 20000, 200, 152
+    sp = make_splats(n, seed=21, device=hip_device)
+    cam = make_camera(3, W, H, device=hip_device)
+    gi, gd, ga = make_upstream_grads(H, W, device=hip_device)
+    gen = torch.Generator().manual_seed(4)
+    raw = {
+        "means3D": sp["means3D"],
+        "shs": sp["shs"],
+        "opacity": torch.logit(sp["opacities"].clamp(0.02, 0.98)),
+        "scaling": torch.log(sp["scales"]),
+        "rotation": sp["rotations"] * (0.5 + 2.0 * torch.rand(n, 1, generator=gen).to(hip_device)),   # |q| != 1
+    }
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.tensor([0.1, 0.2, 0.3], device=hip_device), scale_modifier=0.9, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
+    res = []
+    for fused in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        m2d = torch.zeros_like(p["means3D"], requires_grad=True)
+        r = GaussianRasterizer(rs)
+        if fused:
+            out = r.forward_raw(means3D=p["means3D"], means2D=m2d, opacity_logits=p["opacity"], shs=p["shs"],
+                                log_scales=p["scaling"], quaternions=p["rotation"])
+        else:
+            out = r.forward_ex(means3D=p["means3D"], means2D=m2d, opacities=torch.sigmoid(p["opacity"]), shs=p["shs"],
+                               scales=torch.exp(p["scaling"]), rotations=torch.nn.functional.normalize(p["rotation"]))
+        torch.autograd.backward((out[0], out[2], out[3]), (gi, gd, ga))
+        res.append((out, {k: v.grad.clone() for k, v in p.items()}, m2d.grad.clone()))
+    (oa, ga_, ma), (ob, gb_, mb) = res
+    assert torch.equal(oa[1], ob[1])                                   # radii
+    for i in (0, 2, 3):
+        assert torch.allclose(oa[i], ob[i], atol=2e-5, rtol=1e-4), i
+    for k in ga_:
+        scale = ga_[k].abs().max().item()
+        assert torch.allclose(ga_[k], gb_[k], atol=1e-4 * scale), (k, (ga_[k] - gb_[k]).abs().max().item() / scale)
+    assert torch.allclose(ma, mb, atol=1e-4 * ma.abs().max().item())
