@@ -45,6 +45,10 @@ def parse():
                         "colour gradients, SH gradient rebuilt on every rank (sh_gather_step, ~161 B/splat); 'allreduce' = "
                         "sum-all-reduce of all five gradient tensors (~413 B/splat).  A mode that fails on any rank falls back "
                         "to the next one on all ranks.")
+    p.add_argument("--inputs", choices=["boundary", "raw-split"], default="boundary",
+                   help="'boundary' (default, the reference's call): activated tensors and the concatenated SH tensor; 'raw-split': "
+                        "the optimiser's raw parameters (logits, log-scales, unnormalised quaternions) and the two SH tensors "
+                        "(dc, rest) -- activations and concatenation fused into the kernels (GaussianRasterizer.forward_raw)")
     p.add_argument("--force-dp-path", action="store_true", help="run the chosen --dp-mode step function even with 1 GPU (overhead check)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke-testing the control flow)")
     p.add_argument("--single-device", action="store_true", help="smoke test: every rank uses cuda:0 (needs --backend gloo)")
@@ -108,6 +112,11 @@ def main():
     sp = make_splats(N, seed=1234, device=dev)
     names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
     params = {k: sp[k].clone().requires_grad_(True) for k in names}
+    raw_split = args.inputs == "raw-split" and use_sh
+    if raw_split:
+        raw = {"means3D": sp["means3D"], "opacity": torch.logit(sp["opacities"].clamp(1e-4, 1 - 1e-4)), "scaling": torch.log(sp["scales"]),
+               "rotation": sp["rotations"], "f_dc": sp["shs"][:, :1].contiguous(), "f_rest": sp["shs"][:, 1:].contiguous()}
+        params = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
     gi, gd, ga = make_upstream_grads(H, W, device=dev)
     bg = torch.ones(3, device=dev)
     cams = [make_camera(k, W, H, device=dev) for k in range(8)]
@@ -145,10 +154,15 @@ def main():
         for p in params.values():
             p.grad = None
         means2D = torch.zeros_like(params["means3D"], requires_grad=True)
-        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
-            means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
-            shs=params["shs"] if use_sh else None, colors_precomp=None if use_sh else params["colors_precomp"],
-            scales=params["scales"], rotations=params["rotations"])
+        if raw_split:
+            color, radii, depth, alpha = GaussianRasterizer(rs).forward_raw(
+                means3D=params["means3D"], means2D=means2D, opacity_logits=params["opacity"], shs=params["f_dc"],
+                shs_rest=params["f_rest"], log_scales=params["scaling"], quaternions=params["rotation"])
+        else:
+            color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+                means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                shs=params["shs"] if use_sh else None, colors_precomp=None if use_sh else params["colors_precomp"],
+                scales=params["scales"], rotations=params["rotations"])
         # loss = sum(color*G_img) + sum(depth*G_depth) + sum(alpha*G_alpha) is linear, so its upstream
         # gradients are the fixed G tensors: feed them directly instead of spending ~15 small PyTorch kernels
         # (mul/sum/add and their backward) on a stand-in loss that is not part of the rasterizer.
@@ -231,7 +245,7 @@ def main():
                                    "gather": ", RCCL all-gather of colour gradients + all-reduce of the other per-splat gradients",
                                    "allreduce": ", RCCL sum all-reduce of per-splat gradients"}[state["mode"]] if world > 1 else ""),
                    "splats": N, "width": W, "height": H, "views_per_step": world,
-                   "visible_splats": vis, "tile_instances": R, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
+                   "visible_splats": vis, "tile_instances": R, "inputs": args.inputs, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": dom_bw / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                      "avg_launch_ms": stage_ms[dom]},

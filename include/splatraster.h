@@ -77,6 +77,10 @@ typedef struct SrSplats {
     int raw_params;              /* bit mask of SR_RAW_*: inputs that arrive as the optimiser's raw parameters; the activation of
                                   * reference scene/gaussian_model.py:64-86 is applied inside the preprocess kernels and its
                                   * derivative inside sr_backward (the gradients are then w.r.t. the raw parameters) */
+    const float* shs_rest;       /* NULL, or device [N,15,3]: the SH coefficients arrive as the reference stores them, `shs` =
+                                  * `_features_dc` [N,1,3] and `shs_rest` = `_features_rest` [N,15,3] (scene/gaussian_model.py:40-41),
+                                  * instead of their per-iteration concatenation (:79-82); needs sh_coeffs == 16, both 16-byte
+                                  * aligned.  The gradients then go to SrGrads.dL_dshs [N,1,3] and dL_dshs_rest [N,15,3]. */
 } SrSplats;
 
 #define SR_RAW_SCALES 1    /* scales = log-scales:        get_scaling  = exp(_scaling)          (gaussian_model.py:64-68) */
@@ -95,6 +99,7 @@ typedef struct SrGrads {
     float* dL_dcolors;    /* [N,3] or NULL.  With SH input, dL_dshs == NULL and dL_dcolors != NULL selects the colour-gradient
                            * mode: the clamp-masked dL/dcolour is written instead of dL/dsh (view-parallel exchange, sr_sh_backward);
                            * the gradient through the view direction is still added to dL_dmeans3D. */
+    float* dL_dshs_rest;  /* [N,15,3] with SrSplats.shs_rest, else NULL */
 } SrGrads;
 
 int sr_version(void);

@@ -24,13 +24,13 @@ class SrView(C.Structure):
 class SrSplats(C.Structure):
     _fields_ = [("count", C.c_int), ("means3D", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("shs", C.c_void_p),
-                ("colors_precomp", C.c_void_p), ("raw_params", C.c_int)]
+                ("colors_precomp", C.c_void_p), ("raw_params", C.c_int), ("shs_rest", C.c_void_p)]
 
 
 class SrGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p),
-                ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p)]
+                ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
 # every symbol include/splatraster.h declares: name -> (restype, argtypes)

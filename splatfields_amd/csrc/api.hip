@@ -1,4 +1,5 @@
 // C ABI of libsplatraster.so (see include/splatraster.h for what each entry replaces).
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -72,7 +73,13 @@ int validate(const SrView* view, const SrSplats* s) {
         if (s->shs) {
             if (view->sh_degree < 0 || view->sh_degree > 3) return fail("sh_degree must be 0..3");
             if (view->sh_coeffs < (view->sh_degree + 1) * (view->sh_degree + 1)) return fail("shs holds fewer coefficients than sh_degree needs");
-        }
+            if (s->shs_rest) {
+                if (view->sh_coeffs != 16) return fail("shs_rest (dc + rest SH tensors) needs sh_coeffs == 16");
+                if ((reinterpret_cast<uintptr_t>(s->shs) | reinterpret_cast<uintptr_t>(s->shs_rest)) & 15u) return fail("shs / shs_rest must be 16-byte aligned");
+            }
+        } else if (s->shs_rest) return fail("shs_rest without shs");
+        if (s->raw_params & ~(SR_RAW_SCALES | SR_RAW_OPACITY | SR_RAW_ROTATIONS)) return fail("unknown bits in raw_params");
+        if (s->cov3D_precomp && (s->raw_params & (SR_RAW_SCALES | SR_RAW_ROTATIONS))) return fail("raw scales/rotations with cov3D_precomp");
     }
     if ((sr::tiles_x(view->image_width) > 65535) || (sr::tiles_y(view->image_height) > 65535)) return fail("image too large");
     return 0;
@@ -94,7 +101,7 @@ sr::SplatsK make_splats(const SrSplats* s) {
     sr::SplatsK k;
     k.N = s->count; k.means3D = s->means3D; k.opacities = s->opacities; k.scales = s->scales;
     k.rotations = s->rotations; k.cov3D = s->cov3D_precomp; k.shs = s->shs; k.colors = s->colors_precomp;
-    k.raw = s->raw_params;
+    k.raw = s->raw_params; k.shs_rest = s->shs_rest;
     return k;
 }
 
@@ -214,6 +221,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     if (!geom || !binning || !image || !dL_dcolor || !scratch || !grads) return fail("null buffer");
     if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
     if (splats->count > 0 && splats->shs && !grads->dL_dshs && !grads->dL_dcolors) return fail("dL_dshs (or dL_dcolors for the colour-gradient mode) missing");
+    if (splats->count > 0 && splats->shs_rest && grads->dL_dshs && !grads->dL_dshs_rest) return fail("dL_dshs_rest missing");
     if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
     if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
     if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
@@ -235,6 +243,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
     gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
     gr.shs = s.shs ? grads->dL_dshs : nullptr;
+    gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
     gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
     { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, reached, gr, st); }
     SR_TRY(after_launch(view, st, "preprocess_backward"));

@@ -9,11 +9,12 @@ struct SplatsK {
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* cov3D; const float* shs; const float* colors;
     int raw;  // SR_RAW_* bits: activations applied on load, their derivatives on the way out
+    const float* shs_rest;  // non-NULL: shs = dc [N,1,3], shs_rest = [N,15,3]
 };
 
 struct GradsK {
     float* means3D; float* means2D; float* opacity; float* scales; float* rotations; float* cov3D;
-    float* shs; float* colors;
+    float* shs; float* colors; float* shs_rest;
 };
 
 // preprocess.hip

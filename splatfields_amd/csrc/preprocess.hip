@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     }
     if constexpr (STAGE_SH) {
         const size_t first = (size_t)blockIdx.x * kBlock;
-        stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
+        if (s.shs_rest) stage_sh_in_split(s_sh, s.shs, s.shs_rest, first, min(kBlock, s.N - (int)first));
+        else stage_sh_in(s_sh, s.shs, first, min(kBlock, s.N - (int)first));
         __syncthreads();
     }
     if (s.raw) { float qn; activate_inputs(s.raw, sc_in, opac_in, q_in, qn); }
@@ -308,7 +309,8 @@ void launch_preprocess(const ViewK& v, const SplatsK& s, const Geom& g, int* rad
     const bool atomic = !use_count_matrix(v);
     if (atomic) hipMemsetAsync(g.tile_count, 0, sizeof(uint32_t) * (size_t)v.gx * v.gy, st);
     if (nb <= 0) return;
-    const bool stage = s.shs && v.sh_coeffs == 16 && v.sh_degree >= 2;  // below degree 2 only <= 48 of the 192 bytes are needed
+    // below degree 2 only <= 48 of the 192 bytes are needed; the two-tensor SH input always goes through the staging
+    const bool stage = s.shs && v.sh_coeffs == 16 && (v.sh_degree >= 2 || s.shs_rest);
     if (stage && atomic) hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
     else if (stage) hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
     else if (atomic) hipLaunchKernelGGL((k_preprocess<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii);
@@ -631,7 +633,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     if constexpr (STAGE_SH && !SH_TO_COLORS) {
         __syncthreads();
         const size_t first = (size_t)blockIdx.x * kBlock;
-        stage_sh_out(s_sh, gr.shs, first, min(kBlock, s.N - (int)first));
+        if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, s.N - (int)first));
+        else stage_sh_out(s_sh, gr.shs, first, min(kBlock, s.N - (int)first));
     }
 }
 

@@ -112,9 +112,14 @@ class _ViewPack:
             self.campos.data_ptr(), self.bg.data_ptr())
 
 
-def _splats_struct(n, means3D, opacities, scales, rotations, cov3D, shs, colors, raw_params: int = 0) -> _lib.SrSplats:
+def _splats_struct(n, means3D, opacities, scales, rotations, cov3D, shs, colors, raw_params: int = 0, shs_rest=None) -> _lib.SrSplats:
     g = lambda t: None if t is None else t.data_ptr()
-    return _lib.SrSplats(int(n), g(means3D), g(opacities), g(scales), g(rotations), g(cov3D), g(shs), g(colors), int(raw_params))
+    return _lib.SrSplats(int(n), g(means3D), g(opacities), g(scales), g(rotations), g(cov3D), g(shs), g(colors), int(raw_params),
+                         g(shs_rest))
+
+
+def _aligned16(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return t if (t is None or t.data_ptr() % 16 == 0) else t.clone()
 
 
 def _stream_ptr(device) -> C.c_void_p:
@@ -126,7 +131,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0):
+                raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0, sh_rest=None):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -147,6 +152,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sh_c is not None and (sh_c.dim() != 3 or sh_c.shape[2] != 3):
             raise RuntimeError("shs must have dimensions (num_points, K, 3)")
         sh_coeffs = 0 if sh_c is None else int(sh_c.shape[1])
+        rest_c = None
+        if _opt(sh_rest) is not None:
+            # the reference's two SH parameters, `_features_dc` [N,1,3] + `_features_rest` [N,15,3], without concatenating them
+            rest_c = _aligned16(f(sh_rest))
+            sh_c = _aligned16(sh_c)
+            if sh_c is None or sh_c.shape[1] != 1 or rest_c.dim() != 3 or tuple(rest_c.shape) != (n, 15, 3):
+                raise RuntimeError("with shs_rest, shs must be [N,1,3] (dc) and shs_rest [N,15,3]")
+            sh_coeffs = 16
 
         view = _ViewPack.get(raster_settings, dev, sh_coeffs)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -160,6 +173,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.n = n
         ctx.opac_shape = tuple(opacities.shape)
         ctx.in_dtypes = [None if t is None else t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)]
+        ctx.rest_dtype = None if rest_c is None else sh_rest.dtype
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         if n == 0:
@@ -172,7 +186,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
-            splats = _splats_struct(n, means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, raw_params)
+            splats = _splats_struct(n, means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, raw_params, rest_c)
             geom = torch.empty(lib.sr_geom_bytes(n, H, W), dtype=torch.uint8, device=dev)
             image = torch.empty(lib.sr_image_bytes(H, W), dtype=torch.uint8, device=dev)
             inst = C.c_longlong(0)
@@ -205,7 +219,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.instances = instances
         ctx.capacity = capacity
         ctx.view_pack = view
-        ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image)
+        ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image, rest_c)
         return color, radii, depth, alpha
 
     @staticmethod
@@ -213,9 +227,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         n = ctx.n
         if n == 0:
-            return (None,) * 11
+            return (None,) * 12
         lib = _lib.load()
-        means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image = ctx.saved_tensors
+        means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image, sh_rest = ctx.saved_tensors
         dev = means3D.device
         H, W = int(rs.image_height), int(rs.image_width)
         g = lambda t: _as_input(t, dev)
@@ -232,12 +246,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         sink = ctx.color_grad_sink if sh is not None else None
         d_sh = new(*sh.shape) if (sh is not None and sink is None) else None
         d_col = new(n, 3) if (col is not None or sink is not None) else None
+        d_rest = new(*sh_rest.shape) if (sh_rest is not None and d_sh is not None) else None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
-            splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col, ctx.raw_params)
+            splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col, ctx.raw_params, sh_rest)
             scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.capacity), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
-            grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col))
+            grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col), p(d_rest))
             _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
                                        _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
                                        _ptr(scratch), C.byref(grads), stream))
@@ -248,16 +263,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = [d_means3D, d_means2D, d_sh, d_col, d_opac.reshape(ctx.opac_shape), d_sc, d_rot, d_cov]
         # the kernels compute in fp32; hand each gradient back in its input's dtype (fp64 / fp16 callers)
         grads = [g_ if (g_ is None or dt is None or g_.dtype == dt) else g_.to(dt) for g_, dt in zip(grads, ctx.in_dtypes)]
-        return (*grads, None, None, None)
+        if d_rest is not None and ctx.rest_dtype is not None and d_rest.dtype != ctx.rest_dtype:
+            d_rest = d_rest.to(ctx.rest_dtype)
+        return (*grads, None, None, None, d_rest)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, color_grad_sink=None, raw_params: int = 0):
+                        raster_settings, color_grad_sink=None, raw_params: int = 0, sh_rest=None):
     """Returns (color, radii, depth, alpha).  ``alpha`` (= 1 - final transmittance) is the fused equivalent of
     the reference's second rasterization with white colours on a black background
     (gaussian_renderer/__init__.py:104-115)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params)
+                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -288,18 +305,22 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
     def forward_ex(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                   cov3D_precomp=None, color_grad_sink=None):
+                   cov3D_precomp=None, color_grad_sink=None, shs_rest=None):
         """Same as ``forward`` plus the fused alpha image: (color, radii, depth, alpha).
 
         ``color_grad_sink`` (a list, SH path only): the backward appends the clamp-masked dL/dcolour [N,3] of this view to
         it and returns no gradient for ``shs`` -- used by the view-parallel step, which exchanges colour gradients and
-        rebuilds the SH gradient of all views locally (splatfields_amd/view_parallel.py)."""
+        rebuilds the SH gradient of all views locally (splatfields_amd/view_parallel.py).
+
+        ``shs_rest``: pass the reference's two SH parameters as they are stored, ``shs=_features_dc`` [N,1,3] and
+        ``shs_rest=_features_rest`` [N,15,3] (scene/gaussian_model.py:40-41), instead of ``get_features`` -- the per-iteration
+        ``torch.cat`` (:79-82, 192 B/splat copied forward and split again in backward) disappears; each gets its gradient."""
         self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, color_grad_sink)
+                                   self.raster_settings, color_grad_sink, 0, shs_rest)
 
     def forward_raw(self, means3D, means2D, opacity_logits, shs=None, colors_precomp=None, log_scales=None, quaternions=None,
-                    color_grad_sink=None):
+                    color_grad_sink=None, shs_rest=None):
         """``forward_ex`` on the optimiser's RAW parameters: ``_opacity`` (logits), ``_scaling`` (log-scales, [N,3]) and
         ``_rotation`` (unnormalised quaternions) as ``GaussianModel`` stores them (reference scene/gaussian_model.py:64-86).
         ``sigmoid`` / ``exp`` / ``normalize`` run inside the preprocess kernels and their derivatives inside the backward,
@@ -308,7 +329,7 @@ class GaussianRasterizer(nn.Module):
         self._check(shs, colors_precomp, log_scales, quaternions, None)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacity_logits, log_scales, quaternions, None,
                                    self.raster_settings, color_grad_sink,
-                                   _lib.SR_RAW_SCALES | _lib.SR_RAW_OPACITY | _lib.SR_RAW_ROTATIONS)
+                                   _lib.SR_RAW_SCALES | _lib.SR_RAW_OPACITY | _lib.SR_RAW_ROTATIONS, shs_rest)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):

@@ -46,14 +46,14 @@ def test_struct_layouts_match_header():
     from splatfields_amd import _lib
     # 9 x 4-byte scalars, padded to 8, then 4 pointers
     assert C.sizeof(_lib.SrView) == 40 + 4 * 8
-    assert C.sizeof(_lib.SrSplats) == 8 + 7 * 8 + 8   # count (padded), 7 pointers, raw_params (padded)
-    assert C.sizeof(_lib.SrGrads) == 8 * 8
+    assert C.sizeof(_lib.SrSplats) == 8 + 7 * 8 + 8 + 8   # count (padded), 7 pointers, raw_params (padded), shs_rest
+    assert C.sizeof(_lib.SrGrads) == 9 * 8
 
 
 def test_argument_validation_errors_without_gpu(lib):
     from splatfields_amd import _lib
     view = _lib.SrView(64, 64, 0.5, 0.5, 1.0, 0, 0, 0, 0, None, None, None, None)
-    splats = _lib.SrSplats(0, None, None, None, None, None, None, None, 0)
+    splats = _lib.SrSplats(0, None, None, None, None, None, None, None, 0, None)
     inst = C.c_longlong(0)
     rc = lib.sr_forward_prepare(C.byref(view), C.byref(splats), None, None, C.byref(inst), None)
     assert rc != 0 and b"device pointers" in lib.sr_last_error()

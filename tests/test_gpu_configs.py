@@ -189,3 +189,36 @@ def test_raw_parameter_path_equals_activations_in_torch(hip_device):
         scale = ga_[k].abs().max().item()
         assert torch.allclose(ga_[k], gb_[k], atol=1e-4 * scale), (k, (ga_[k] - gb_[k]).abs().max().item() / scale)
     assert torch.allclose(ma, mb, atol=1e-4 * ma.abs().max().item())
+
+
+@pytest.mark.parametrize("n", [20001, 256, 7])   # 45 n floats of `rest` is not a multiple of 4 for odd n: partial last float4
+def test_two_tensor_sh_input_equals_concatenated(hip_device, n):
+    """shs=_features_dc [N,1,3] + shs_rest=_features_rest [N,15,3] (scene/gaussian_model.py:40-41) must give bit-identical
+    images and the gradients of the concatenated tensor (:79-82), split."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 120, 88
+    sp = make_splats(n, seed=33, device=hip_device, mean_scale=0.05 if n < 1000 else None)
+    cam = make_camera(2, W, H, device=hip_device)
+    gi, gd, ga = make_upstream_grads(H, W, device=hip_device)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.ones(3, device=hip_device), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False)
+    for deg in (3, 1):
+        rs_d = rs._replace(sh_degree=deg)
+        outs = []
+        for split in (False, True):
+            dc = sp["shs"][:, :1].clone().requires_grad_(True)
+            rest = sp["shs"][:, 1:].clone().requires_grad_(True)
+            geo = {k: sp[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+            kw = dict(means3D=geo["means3D"], means2D=torch.zeros_like(geo["means3D"]), opacities=geo["opacities"],
+                      scales=geo["scales"], rotations=geo["rotations"])
+            if split:
+                kw.update(shs=dc, shs_rest=rest)
+            else:
+                kw.update(shs=torch.cat((dc, rest), dim=1))
+            c, r, d, a = GaussianRasterizer(rs_d).forward_ex(**kw)
+            torch.autograd.backward((c, d, a), (gi, gd, ga))
+            outs.append((c.detach(), d.detach(), a.detach(), r, dc.grad, rest.grad, geo["means3D"].grad, geo["opacities"].grad))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
