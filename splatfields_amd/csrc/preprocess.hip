@@ -239,12 +239,15 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         d.x *= inv_len; d.y *= inv_len; d.z *= inv_len;
                         float B[16];
                         sh_basis(v.sh_degree, d, B);
-                        const float* sh = STAGE_SH ? reinterpret_cast<const float*>(&s_sh[threadIdx.x * kShRowF4])
-                                                   : s.shs + (size_t)idx * v.sh_coeffs * 3;
+                        // float j = 3k + c of this splat's coefficients: sh_lo[j] for the dc triple, sh_hi[j] for the rest
+                        // (the same row unless the two-tensor input is staged as two spans)
+                        float *sh_lo, *sh_hi;
+                        if (STAGE_SH) sh_row_pointers(s_sh, s.shs_rest != nullptr, threadIdx.x, sh_lo, sh_hi);
+                        else sh_lo = sh_hi = const_cast<float*>(s.shs) + (size_t)idx * v.sh_coeffs * 3;
                         const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
-                        rgb = make_float3(0.f, 0.f, 0.f);
-                        for (int k = 0; k < nb; ++k) {
-                            rgb.x += B[k] * sh[3 * k]; rgb.y += B[k] * sh[3 * k + 1]; rgb.z += B[k] * sh[3 * k + 2];
+                        rgb = make_float3(sh_lo[0] * B[0], sh_lo[1] * B[0], sh_lo[2] * B[0]);
+                        for (int k = 1; k < nb; ++k) {
+                            rgb.x += B[k] * sh_hi[3 * k]; rgb.y += B[k] * sh_hi[3 * k + 1]; rgb.z += B[k] * sh_hi[3 * k + 2];
                         }
                         if (v.sh_degree > 0) {
                             // d colour / d direction while the coefficients are at hand (36 bytes per splat instead of the
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                             for (int ch = 0; ch < 3; ++ch) {
                                 float gk[16];
 #pragma unroll
-                                for (int k = 0; k < 16; ++k) gk[k] = k < nb ? sh[3 * k + ch] : 0.f;
+                                for (int k = 0; k < 16; ++k) gk[k] = k < nb ? (k == 0 ? sh_lo[ch] : sh_hi[3 * k + ch]) : 0.f;
                                 const float3 j = sh_dir_gradient(v.sh_degree, d, gk);
                                 g.dcol_ddir[(size_t)(3 * ch) * s.N + idx] = j.x;
                                 g.dcol_ddir[(size_t)(3 * ch + 1) * s.N + idx] = j.y;
@@ -575,7 +578,9 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     // ---- colour: SH coefficients and view direction, or precomputed colours ----
     if (gr.shs || SH_TO_COLORS) {
         // staged: this thread's LDS row first supplies its SH coefficients, then receives its gradients
-        float* out = STAGE_SH ? reinterpret_cast<float*>(&s_sh[threadIdx.x * kShRowF4]) : gr.shs + (size_t)idx * K * 3;
+        float *out_lo, *out_hi;   // float j = 3k + c of this splat's SH gradient: out_lo[j] for j < 3, out_hi[j] beyond
+        if (STAGE_SH) sh_row_pointers(s_sh, gr.shs_rest != nullptr, threadIdx.x, out_lo, out_hi);
+        else out_lo = out_hi = gr.shs + (size_t)idx * K * 3;
         int nb = 0;
         if (visible) {
             nb = (v.sh_degree + 1) * (v.sh_degree + 1);
@@ -590,7 +595,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             float B[16];
             sh_basis(v.sh_degree, d, B);
             if (!SH_TO_COLORS)
-                for (int k = 0; k < nb; ++k) { out[3 * k] = B[k] * dc.x; out[3 * k + 1] = B[k] * dc.y; out[3 * k + 2] = B[k] * dc.z; }
+                for (int k = 0; k < nb; ++k) {
+                    float* o = k == 0 ? out_lo : out_hi + 3 * k;
+                    o[0] = B[k] * dc.x; o[1] = B[k] * dc.y; o[2] = B[k] * dc.z;
+                }
             if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
             if (v.sh_degree > 0) {
                 // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
@@ -609,7 +617,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                 d_mean.z += (dd_.z - d.z * proj) * inv_len;
             }
         }
-        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { out[3 * k] = 0.f; out[3 * k + 1] = 0.f; out[3 * k + 2] = 0.f; }
+        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { float* o = k == 0 ? out_lo : out_hi + 3 * k; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
     }
     if (s.raw) {  // derivatives of the activations: gradients w.r.t. the raw parameters
         if (s.raw & SR_RAW_SCALES) { d_scale.x *= sc_in.x; d_scale.y *= sc_in.y; d_scale.z *= sc_in.z; }   // d exp = exp

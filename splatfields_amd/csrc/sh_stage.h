@@ -40,78 +40,63 @@ __device__ __forceinline__ void stage_sh_out(const float4* s_sh, float* dst_base
 }
 
 // ---- two source arrays: the reference keeps the SH coefficients as two parameters, `_features_dc` [N,1,3] and
-// `_features_rest` [N,15,3] (scene/gaussian_model.py:40-41), and concatenates them every iteration (:79-82).  These variants
-// fill / drain the same LDS rows (floats 0..2 = dc, 3..47 = rest) straight from / into the two arrays: the 256 splats of a
-// workgroup own one contiguous 3 KiB span of dc and one contiguous 45 KiB span of rest, both moved with 16-byte accesses.
-constexpr int kShRowFloats = kShRowF4 * 4;   // 52
-constexpr int kRestFloats = 45;              // 15 coefficients x 3 channels
+// `_features_rest` [N,15,3] (scene/gaussian_model.py:40-41), and concatenates them every iteration (:79-82).  With the
+// two-tensor input the workgroup's LDS holds the two spans exactly as they lie in memory -- dc: 256 x 3 floats at float 0,
+// rest: 256 x 45 floats at float kShSplitRest -- so staging in and out is a linear 16-byte copy, and splat t reads / writes
+// floats dc[3t..3t+2] and rest[45t..45t+44] (odd strides: conflict-free 4-byte LDS accesses).
+constexpr int kRestFloats = 45;                 // 15 coefficients x 3 channels
+constexpr int kShSplitRest = kBlock * 3;        // float offset of the rest span inside the LDS array (768; 16-byte aligned)
+static_assert((kShSplitRest + kBlock * kRestFloats) * 4 <= kBlock * kShRowF4 * 16, "split layout must fit the padded-row array");
 
-// splat-local float index f of a PER floats-per-splat array -> its LDS float slot (row of the splat, offset OFF inside it)
-template <int PER, int OFF>
-__device__ __forceinline__ void split_slots(int f0, int (&slot)[4]) {
-    const int sp0 = f0 / PER, k0 = f0 - sp0 * PER;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kk = k0 + i, wrap = kk >= PER ? 1 : 0;   // a float4 never spans more than two splats (PER >= 3, handled below)
-        slot[i] = (sp0 + wrap) * kShRowFloats + OFF + kk - wrap * PER;
-    }
-}
-template <>
-__device__ __forceinline__ void split_slots<3, 0>(int f0, int (&slot)[4]) {   // dc: 3 floats per splat, a float4 touches 2 splats
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int f = f0 + i, sp = f / 3; slot[i] = sp * kShRowFloats + (f - sp * 3); }
-}
-
-template <int PER, int OFF, int ITERS>
-__device__ __forceinline__ void stage_in_part(float* s_rows, const float* src, int total_f) {
+template <int ITERS>
+__device__ __forceinline__ void stage_in_linear(float* lds, const float* src, int total_f) {
     float4 tmp[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int f0 = 4 * (it * kBlock + (int)threadIdx.x);
         if (f0 + 3 < total_f) tmp[it] = *reinterpret_cast<const float4*>(src + f0);
-        else {  // last, partial float4 of the array: never read past its end
+        else  // last, partial float4 of the array: never read past its end
             tmp[it] = make_float4(f0 < total_f ? src[f0] : 0.f, f0 + 1 < total_f ? src[f0 + 1] : 0.f,
                                   f0 + 2 < total_f ? src[f0 + 2] : 0.f, 0.f);
-        }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int f0 = 4 * (it * kBlock + (int)threadIdx.x);
-        if (f0 >= total_f) continue;
-        int slot[4];
-        split_slots<PER, OFF>(f0, slot);
-        const float v[4] = {tmp[it].x, tmp[it].y, tmp[it].z, tmp[it].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (f0 + i < total_f) s_rows[slot[i]] = v[i];
+        if (f0 < total_f) *reinterpret_cast<float4*>(lds + f0) = tmp[it];   // the pad floats behind the span are never read
     }
 }
-template <int PER, int OFF, int ITERS>
-__device__ __forceinline__ void stage_out_part(const float* s_rows, float* dst, int total_f) {
+template <int ITERS>
+__device__ __forceinline__ void stage_out_linear(const float* lds, float* dst, int total_f) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int f0 = 4 * (it * kBlock + (int)threadIdx.x);
         if (f0 >= total_f) continue;
-        int slot[4];
-        split_slots<PER, OFF>(f0, slot);
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = f0 + i < total_f ? s_rows[slot[i]] : 0.f;
-        if (f0 + 3 < total_f) *reinterpret_cast<float4*>(dst + f0) = make_float4(v[0], v[1], v[2], v[3]);
+        const float4 v = *reinterpret_cast<const float4*>(lds + f0);
+        if (f0 + 3 < total_f) *reinterpret_cast<float4*>(dst + f0) = v;
         else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) if (f0 + i < total_f) dst[f0 + i] = v[i];
+            dst[f0] = v.x;
+            if (f0 + 1 < total_f) dst[f0 + 1] = v.y;
+            if (f0 + 2 < total_f) dst[f0 + 2] = v.z;
         }
     }
 }
 __device__ __forceinline__ void stage_sh_in_split(float4* s_sh, const float* dc, const float* rest, size_t first_splat, int n_here) {
-    float* rows = reinterpret_cast<float*>(s_sh);
-    stage_in_part<3, 0, 1>(rows, dc + first_splat * 3, n_here * 3);                               // <= 192 float4
-    stage_in_part<kRestFloats, 3, 12>(rows, rest + first_splat * kRestFloats, n_here * kRestFloats);  // <= 2880 float4
+    float* lds = reinterpret_cast<float*>(s_sh);
+    stage_in_linear<1>(lds, dc + first_splat * 3, n_here * 3);                                            // <= 192 float4
+    stage_in_linear<12>(lds + kShSplitRest, rest + first_splat * kRestFloats, n_here * kRestFloats);      // <= 2880 float4
 }
 __device__ __forceinline__ void stage_sh_out_split(const float4* s_sh, float* d_dc, float* d_rest, size_t first_splat, int n_here) {
-    const float* rows = reinterpret_cast<const float*>(s_sh);
-    stage_out_part<3, 0, 1>(rows, d_dc + first_splat * 3, n_here * 3);
-    stage_out_part<kRestFloats, 3, 12>(rows, d_rest + first_splat * kRestFloats, n_here * kRestFloats);
+    const float* lds = reinterpret_cast<const float*>(s_sh);
+    stage_out_linear<1>(lds, d_dc + first_splat * 3, n_here * 3);
+    stage_out_linear<12>(lds + kShSplitRest, d_rest + first_splat * kRestFloats, n_here * kRestFloats);
+}
+
+// Where splat `t` of the workgroup finds float j = 3k + c of its 48 coefficients: j < 3 in `lo`, the rest in `hi` (both
+// indexed with j).  Padded rows (one source tensor): lo == hi == the splat's row.
+__device__ __forceinline__ void sh_row_pointers(float4* s_sh, bool split, int t, float*& lo, float*& hi) {
+    float* base = reinterpret_cast<float*>(s_sh);
+    if (split) { lo = base + 3 * t; hi = base + kShSplitRest + kRestFloats * t - 3; }
+    else lo = hi = base + 4 * kShRowF4 * t;
 }
 
 #endif  // __HIPCC__
