@@ -133,8 +133,8 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
  * sr_binning_bytes(*instances_out) and calls sr_forward_render with instances = *instances_out.
  * The binning buffer is carved for the capacity it was rendered with; pass that same number as `instances`
  * to sr_backward.
- * Threading: the asynchronous read-back uses one pinned word + event per device, so at most one sr_forward /
- * sr_forward_prepare may be in flight per device at a time (calls from one host thread are naturally serial). */
+ * Threading: the asynchronous read-back uses one pinned word + event per (host thread, device); host threads may call
+ * concurrently, each on its own stream and buffers. */
 #define SR_NEED_CAPACITY 2
 int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
                long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,

@@ -35,10 +35,11 @@ struct StageTimer {
     ~StageTimer() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
 };
 
-// Pinned word + event per device for the asynchronous instance-count read-back of sr_forward
-// (the only state the library keeps; created lazily, a few bytes per device).
+// Pinned word + event per (host thread, device) for the asynchronous instance-count read-back of sr_forward
+// (the only state the library keeps besides the profiling counters; created lazily, a few bytes each).  Thread-local, so
+// host threads that drive different streams of one device do not share the read-back word.
 struct HostSync { uint32_t* pinned = nullptr; hipEvent_t ev = nullptr; };
-HostSync g_sync[64];
+thread_local HostSync g_sync[64];
 
 int get_host_sync(HostSync** out) {
     int dev = 0;
