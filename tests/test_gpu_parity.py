@@ -298,3 +298,52 @@ def test_tile_lists_beyond_8192_entries_use_the_global_merge(hip_device, faint):
     # default opacities: order-sensitive (a swapped pair at the front of a list changes the pixel visibly)
     out, g, ref = check_against_oracles(sp, st, grads, hip_device, max_fragile=0.95 if faint else 0.6)
     assert ref.num_rendered / 4 > 8192
+
+
+def test_two_host_threads_on_their_own_streams(hip_device):
+    """The library's only host-side state (the instance-count read-back word) is per host thread: two threads rendering
+    different scenes concurrently on their own streams get exactly what they get alone."""
+    import threading
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    import math
+    scenes = [make_scene(6000, 200, 136, seed=5, view=1), make_scene(9000, 168, 120, seed=6, view=4, mean_scale=0.02)]
+
+    def render_once(i):
+        sp, cam, st, grads = scenes[i]
+        leaf = {k: v.to(hip_device).clone().requires_grad_(True) for k, v in sp.items() if k != "colors_precomp"}
+        rs = GaussianRasterizationSettings(
+            image_height=st.image_height, image_width=st.image_width, tanfovx=st.tanfovx, tanfovy=st.tanfovy,
+            bg=st.bg.to(hip_device), scale_modifier=st.scale_modifier, viewmatrix=st.viewmatrix.to(hip_device),
+            projmatrix=st.projmatrix.to(hip_device), sh_degree=st.sh_degree, campos=st.campos.to(hip_device),
+            prefiltered=False, debug=False)
+        c, r, d, a = GaussianRasterizer(rs).forward_ex(
+            means3D=leaf["means3D"], means2D=torch.zeros_like(leaf["means3D"]), opacities=leaf["opacities"], shs=leaf["shs"],
+            scales=leaf["scales"], rotations=leaf["rotations"])
+        gi, gd, ga = [g.to(hip_device) for g in grads]
+        torch.autograd.backward((c, d, a), (gi, gd, ga))
+        return [c.detach().clone(), d.detach().clone(), leaf["means3D"].grad.clone(), leaf["shs"].grad.clone()]
+
+    alone = [render_once(0), render_once(1)]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=hip_device)):
+                out = None
+                for _ in range(15):
+                    out = render_once(i)
+                torch.cuda.current_stream().synchronize()
+                results[i] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for x, y in zip(alone[i], results[i]):
+            assert torch.equal(x, y)
