@@ -86,6 +86,8 @@ typedef struct SrSplats {
 #define SR_RAW_SCALES 1    /* scales = log-scales:        get_scaling  = exp(_scaling)          (gaussian_model.py:64-68) */
 #define SR_RAW_OPACITY 2   /* opacities = logits:         get_opacity  = sigmoid(_opacity)      (gaussian_model.py:84-86) */
 #define SR_RAW_ROTATIONS 4 /* rotations = unnormalised:   get_rotation = normalize(_rotation)   (gaussian_model.py:70-72) */
+#define SR_FORWARD_ONLY 8  /* no sr_backward will follow this forward (rendering / evaluation): state only the backward reads is not
+                            * written (the 36 B/splat colour-direction Jacobian of the SH path) */
 
 /* Dense per-splat gradient outputs, all written in full by sr_backward (culled splats get zeros). */
 typedef struct SrGrads {

@@ -65,7 +65,7 @@ SYMBOLS = {
 
 PROFILE_STAGES = 7
 SR_NEED_CAPACITY = 2
-SR_RAW_SCALES, SR_RAW_OPACITY, SR_RAW_ROTATIONS = 1, 2, 4
+SR_RAW_SCALES, SR_RAW_OPACITY, SR_RAW_ROTATIONS, SR_FORWARD_ONLY = 1, 2, 4, 8
 _lib = None
 
 

@@ -79,7 +79,7 @@ int validate(const SrView* view, const SrSplats* s) {
                 if ((reinterpret_cast<uintptr_t>(s->shs) | reinterpret_cast<uintptr_t>(s->shs_rest)) & 15u) return fail("shs / shs_rest must be 16-byte aligned");
             }
         } else if (s->shs_rest) return fail("shs_rest without shs");
-        if (s->raw_params & ~(SR_RAW_SCALES | SR_RAW_OPACITY | SR_RAW_ROTATIONS)) return fail("unknown bits in raw_params");
+        if (s->raw_params & ~(SR_RAW_SCALES | SR_RAW_OPACITY | SR_RAW_ROTATIONS | SR_FORWARD_ONLY)) return fail("unknown bits in raw_params");
         if (s->cov3D_precomp && (s->raw_params & (SR_RAW_SCALES | SR_RAW_ROTATIONS))) return fail("raw scales/rotations with cov3D_precomp");
     }
     if ((sr::tiles_x(view->image_width) > 65535) || (sr::tiles_y(view->image_height) > 65535)) return fail("image too large");
@@ -224,6 +224,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     if (splats->count > 0 && splats->shs && !grads->dL_dshs && !grads->dL_dcolors) return fail("dL_dshs (or dL_dcolors for the colour-gradient mode) missing");
     if (splats->count > 0 && splats->shs_rest && grads->dL_dshs && !grads->dL_dshs_rest) return fail("dL_dshs_rest missing");
     if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
+    if (splats->raw_params & SR_FORWARD_ONLY) return fail("the forward of these buffers was run with SR_FORWARD_ONLY");
     if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
     if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         for (int k = 1; k < nb; ++k) {
                             rgb.x += B[k] * sh_hi[3 * k]; rgb.y += B[k] * sh_hi[3 * k + 1]; rgb.z += B[k] * sh_hi[3 * k + 2];
                         }
-                        if (v.sh_degree > 0) {
+                        if (v.sh_degree > 0 && !(s.raw & SR_FORWARD_ONLY)) {
                             // d colour / d direction while the coefficients are at hand (36 bytes per splat instead of the
                             // backward re-reading 192)
 #pragma unroll

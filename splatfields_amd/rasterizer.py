@@ -168,6 +168,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(n, dtype=torch.int32, device=dev)  # k_preprocess writes every element
         ctx.raster_settings = raster_settings
         ctx.color_grad_sink = color_grad_sink
+        # nothing to differentiate (rendering / evaluation under no_grad): the forward skips what only the backward reads
+        if not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]):
+            raw_params = int(raw_params) | _lib.SR_FORWARD_ONLY
         ctx.raw_params = int(raw_params)
         ctx.sh_coeffs = sh_coeffs
         ctx.n = n

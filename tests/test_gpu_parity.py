@@ -347,3 +347,20 @@ def test_two_host_threads_on_their_own_streams(hip_device):
     for i in range(2):
         for x, y in zip(alone[i], results[i]):
             assert torch.equal(x, y)
+
+
+def test_forward_only_rendering_matches_the_training_forward(hip_device):
+    """Under no_grad the facade sets SR_FORWARD_ONLY (state only the backward reads is skipped): same images."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sp, cam, st, grads = make_scene(5000, 144, 112, view=2)
+    out_train, _ = run_hip(sp, st, grads, hip_device)
+    rs = GaussianRasterizationSettings(
+        image_height=st.image_height, image_width=st.image_width, tanfovx=st.tanfovx, tanfovy=st.tanfovy,
+        bg=st.bg.to(hip_device), scale_modifier=st.scale_modifier, viewmatrix=st.viewmatrix.to(hip_device),
+        projmatrix=st.projmatrix.to(hip_device), sh_degree=st.sh_degree, campos=st.campos.to(hip_device),
+        prefiltered=False, debug=False)
+    d = {k: v.to(hip_device) for k, v in sp.items()}
+    with torch.no_grad():
+        c, r, dep = GaussianRasterizer(rs)(means3D=d["means3D"], means2D=torch.zeros_like(d["means3D"]), opacities=d["opacities"],
+                                           shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+    assert torch.equal(c.cpu(), out_train["color"]) and torch.equal(dep.cpu(), out_train["depth"]) and torch.equal(r.cpu(), out_train["radii"])
