@@ -364,3 +364,38 @@ def test_forward_only_rendering_matches_the_training_forward(hip_device):
         c, r, dep = GaussianRasterizer(rs)(means3D=d["means3D"], means2D=torch.zeros_like(d["means3D"]), opacities=d["opacities"],
                                            shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
     assert torch.equal(c.cpu(), out_train["color"]) and torch.equal(dep.cpu(), out_train["depth"]) and torch.equal(r.cpu(), out_train["radii"])
+
+
+def test_needle_and_pancake_splats(hip_device):
+    """Extreme anisotropy (axis ratios up to 1:300).  det = ac - b^2 of the 2-D covariance cancels to ~1e-5 of its terms
+    there, so NO fp32 implementation (upstream's included) agrees with fp64 to 1e-4; what must hold is that the kernels --
+    completed-square exponent (p, s, q), exact sub-tile support test -- are no less accurate than the plain fp32
+    restatement of the published formulas (the C oracle), measured against the fp64 oracle."""
+    n = 3000
+    sp, cam, st, grads = make_scene(n, 144, 112, view=6, mean_scale=0.01)
+    gen = torch.Generator().manual_seed(17)
+    stretch = torch.ones(n, 3)
+    axis = torch.randint(0, 3, (n,), generator=gen)
+    stretch[torch.arange(n), axis] = 10.0 ** (torch.rand(n, generator=gen) * 2.5)   # one axis up to ~300x longer
+    flat = torch.rand(n, generator=gen) < 0.3                                        # pancakes: one axis 100x shorter
+    stretch[flat] = 1.0
+    stretch[flat, axis[flat]] = 0.01
+    sp["scales"] = sp["scales"] * stretch
+    out, g = run_hip(sp, st, grads, hip_device)
+    ref, gr = O.fwd_bwd(sp, st, *grads, use_sh=True, dtype=torch.float64)
+    cout, cg, _ = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2])
+    for k, r in (("color", ref.color), ("depth", ref.depth), ("alpha", ref.alpha)):
+        err_hip = (out[k].double() - r.detach()).abs()
+        err_c = (cout[k].double() - r.detach()).abs()
+        # mean error: a handful of threshold pixels differ between any two fp32 evaluations; the bulk must not be worse
+        assert err_hip.mean().item() <= 1.5 * err_c.mean().item() + 1e-6, (k, err_hip.mean().item(), err_c.mean().item())
+        assert err_hip.max().item() <= 3.0 * err_c.max().item() + 2e-2, (k, err_hip.max().item(), err_c.max().item())
+    # gradients: the chain conic -> cov2D multiplies rounding noise by (ac / det)^2 for the needles, so the geometric
+    # gradients of ANY fp32 evaluation are percent-level noisy here (C oracle: 1-5 % L2 vs fp64; measured for the kernels:
+    # 2-8 %, their v_exp/v_rcp are 1-ulp instructions); they must stay of that order, the well-conditioned ones tight
+    for k in g:
+        nrm = gr[k].double().norm().item()
+        e_hip = (g[k].double() - gr[k].double()).norm().item()
+        e_c = (cg[k].double() - gr[k].double()).norm().item()
+        factor = 5.0 if k in ("means3D", "scales", "rotations") else 2.0
+        assert e_hip <= factor * e_c + 1e-3 * nrm, (k, e_hip / nrm, e_c / nrm)
