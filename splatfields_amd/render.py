@@ -61,3 +61,36 @@ def render(viewpoint_camera, gaussian_dict: dict, pipe, bg_color: torch.Tensor, 
             opacity_image = alpha
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "opacity": opacity_image, "depth": depth}
+
+
+def render_model(viewpoint_camera, gaussians, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, return_opacity=True):
+    """``render`` for the static / warm-up branch of reference train.py:41-50, taking the ``GaussianModel`` itself instead
+    of the dict of its accessors: the raw parameters (``_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation``,
+    scene/gaussian_model.py:38-46) go to the rasterizer as they are stored, and ``exp`` / ``sigmoid`` / ``normalize`` /
+    ``cat`` (:64-86) happen inside its preprocess kernels (``GaussianRasterizer.forward_raw``).  Same result dict as
+    ``render``; gradients arrive on the raw parameters."""
+    means3D = gaussians._xyz
+    log_scales = gaussians._scaling
+    if log_scales.shape[-1] == 1:  # use_isotropic (gaussian_model.py:64-68): the accessor repeats the single scale
+        log_scales = log_scales.expand(-1, 3)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=int(gaussians.active_sh_degree),
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+    dc, rest = gaussians._features_dc, gaussians._features_rest
+    if rest.shape[1] == 15:
+        kw = dict(shs=dc, shs_rest=rest)
+    else:  # other SH widths: the concatenated tensor, as the accessor builds it
+        kw = dict(shs=torch.cat((dc, rest), dim=1))
+    rendered_image, radii, depth, alpha = GaussianRasterizer(raster_settings=rs).forward_raw(
+        means3D=means3D, means2D=screenspace_points, opacity_logits=gaussians._opacity, log_scales=log_scales,
+        quaternions=gaussians._rotation, **kw)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "opacity": alpha if return_opacity else None, "depth": depth}

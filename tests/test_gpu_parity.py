@@ -15,6 +15,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import torch_oracle as O
+from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
 from tests.helpers import grad_error, image_errors, make_scene, radii_mismatch, run_hip
 from tests.test_oracle_cross import load_golden
 
@@ -399,3 +400,42 @@ def test_needle_and_pancake_splats(hip_device):
         e_c = (cg[k].double() - gr[k].double()).norm().item()
         factor = 5.0 if k in ("means3D", "scales", "rotations") else 2.0
         assert e_hip <= factor * e_c + 1e-3 * nrm, (k, e_hip / nrm, e_c / nrm)
+
+
+def test_render_model_equals_render_of_the_accessors(hip_device):
+    """render_model(GaussianModel-like object) == render(dict of its accessors) (reference train.py:41-50), isotropic too."""
+    from types import SimpleNamespace
+    from splatfields_amd.render import render, render_model
+    n, W, H = 8000, 176, 120
+    base = make_splats(n, seed=9, device=hip_device)
+    cam = make_camera(5, W, H, device=hip_device)
+    bg = torch.tensor([0.3, 0.1, 0.6], device=hip_device)
+    gi, gd, ga = make_upstream_grads(H, W, device=hip_device)
+    for isotropic in (False, True):
+        raw = dict(_xyz=base["means3D"].clone(), _features_dc=base["shs"][:, :1].clone(), _features_rest=base["shs"][:, 1:].clone(),
+                   _opacity=torch.logit(base["opacities"].clamp(0.02, 0.98)),
+                   _scaling=torch.log(base["scales"][:, :1] if isotropic else base["scales"]).clone(), _rotation=base["rotations"] * 1.7)
+        res = []
+        for fused in (False, True):
+            p = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+            model = SimpleNamespace(active_sh_degree=3, **p)
+            if fused:
+                out = render_model(cam, model, SimpleNamespace(debug=False), bg)
+            else:
+                sc = torch.exp(p["_scaling"])
+                d = {"means3D": p["_xyz"], "active_sh_degree": 3, "gaussian_opacity": torch.sigmoid(p["_opacity"]),
+                     "gaussian_features": torch.cat((p["_features_dc"], p["_features_rest"]), dim=1),
+                     "gaussian_scales": sc.repeat(1, 3) if isotropic else sc,
+                     "gaussian_rotations": torch.nn.functional.normalize(p["_rotation"])}
+                out = render(cam, d, SimpleNamespace(debug=False), bg)
+            torch.autograd.backward((out["render"], out["depth"], out["opacity"]), (gi, gd, ga))
+            res.append((out, {k: v.grad.clone() for k, v in p.items()}, out["viewspace_points"].grad.clone()))
+        (oa, ga_, va), (ob, gb_, vb) = res
+        assert torch.equal(oa["radii"], ob["radii"]) and torch.equal(oa["visibility_filter"], ob["visibility_filter"])
+        for k in ("render", "depth", "opacity"):
+            assert torch.allclose(oa[k], ob[k], atol=2e-5, rtol=1e-4), k
+        for k in ga_:
+            scale = ga_[k].abs().max().item()
+            # (isotropic splats do not depend on their rotation: that gradient is rounding noise around 0 on both sides)
+            assert torch.allclose(ga_[k], gb_[k], atol=1e-4 * scale + 1e-9), (isotropic, k, (ga_[k] - gb_[k]).abs().max().item() / scale)
+        assert torch.allclose(va, vb, atol=1e-4 * va.abs().max().item())
