@@ -42,7 +42,8 @@ struct Geom {
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive
     uint32_t* touched;   // [N] instances emitted by this splat
     uint32_t* offsets;   // [N] exclusive prefix of `touched`
-    float* dcol_ddir;    // [9][N] (SH path, degree > 0) d colour_c / d unit-direction_axis before the >= 0 clamp, row 3c + axis:
+    float* dcol_ddir;    // (SH path, degree > 0) J[3c + axis] = d colour_c / d unit-direction_axis before the >= 0 clamp, stored as
+                         //     float4[N] (J0..J3), float4[N] (J4..J7), float[N] (J8):
                          //     written by the forward so that the backward never re-reads the 192-byte SH block of a splat
     uint32_t* depth_bits; // [N] view depth as float bits (> 0.2, so they sort as integers): the scatter reads 4 B instead of a 64-B record
     uint8_t* flags;      // [N]

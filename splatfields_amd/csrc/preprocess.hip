@@ -252,16 +252,20 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         if (v.sh_degree > 0 && !(s.raw & SR_FORWARD_ONLY)) {
                             // d colour / d direction while the coefficients are at hand (36 bytes per splat instead of the
                             // backward re-reading 192)
+                            float jac[9];
 #pragma unroll
                             for (int ch = 0; ch < 3; ++ch) {
                                 float gk[16];
 #pragma unroll
                                 for (int k = 0; k < 16; ++k) gk[k] = k < nb ? (k == 0 ? sh_lo[ch] : sh_hi[3 * k + ch]) : 0.f;
                                 const float3 j = sh_dir_gradient(v.sh_degree, d, gk);
-                                g.dcol_ddir[(size_t)(3 * ch) * s.N + idx] = j.x;
-                                g.dcol_ddir[(size_t)(3 * ch + 1) * s.N + idx] = j.y;
-                                g.dcol_ddir[(size_t)(3 * ch + 2) * s.N + idx] = j.z;
+                                jac[3 * ch] = j.x; jac[3 * ch + 1] = j.y; jac[3 * ch + 2] = j.z;
                             }
+                            // two 16-byte stores + one 4-byte store per splat (three coalesced streams)
+                            float4* jq = reinterpret_cast<float4*>(g.dcol_ddir);
+                            jq[idx] = make_float4(jac[0], jac[1], jac[2], jac[3]);
+                            jq[(size_t)s.N + idx] = make_float4(jac[4], jac[5], jac[6], jac[7]);
+                            g.dcol_ddir[(size_t)8 * s.N + idx] = jac[8];
                         }
                         rgb.x += 0.5f; rgb.y += 0.5f; rgb.z += 0.5f;
                         if (rgb.x < 0.f) { flags |= kFlagClampR; rgb.x = 0.f; }
@@ -602,14 +606,12 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
             if (v.sh_degree > 0) {
                 // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
-                float3 dd_ = make_float3(0.f, 0.f, 0.f);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float w = ch == 0 ? dc.x : (ch == 1 ? dc.y : dc.z);
-                    dd_.x += w * g.dcol_ddir[(size_t)(3 * ch) * s.N + idx];
-                    dd_.y += w * g.dcol_ddir[(size_t)(3 * ch + 1) * s.N + idx];
-                    dd_.z += w * g.dcol_ddir[(size_t)(3 * ch + 2) * s.N + idx];
-                }
+                const float4* jq = reinterpret_cast<const float4*>(g.dcol_ddir);
+                const float4 j0 = jq[idx], j1 = jq[(size_t)s.N + idx];
+                const float j22 = g.dcol_ddir[(size_t)8 * s.N + idx];
+                const float3 dd_ = make_float3(dc.x * j0.x + dc.y * j0.w + dc.z * j1.z,
+                                               dc.x * j0.y + dc.y * j1.x + dc.z * j1.w,
+                                               dc.x * j0.z + dc.y * j1.y + dc.z * j22);
                 // through the normalisation d = dv / |dv|
                 const float proj = dot3(d, dd_);
                 d_mean.x += (dd_.x - d.x * proj) * inv_len;
