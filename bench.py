@@ -30,8 +30,8 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:35 (6.29e12 mea
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--splats", type=int, default=1_000_000)
     p.add_argument("--width", type=int, default=800)
     p.add_argument("--height", type=int, default=800)
