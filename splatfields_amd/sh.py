@@ -39,9 +39,11 @@ def sh_forward(means3D: torch.Tensor, shs: torch.Tensor, campos: torch.Tensor, s
     return colors, clamped
 
 
-def sh_forward_views(means3D: torch.Tensor, shs: torch.Tensor, campos_views: torch.Tensor, sh_degree: int, want_keep: bool = True):
+def sh_forward_views(means3D: torch.Tensor, shs: torch.Tensor, campos_views: torch.Tensor, sh_degree: int, want_keep: bool = True,
+                     out: torch.Tensor = None):
     """Colours of the same splats for V cameras in one pass: -> (colors [V,N,3], keep [V,N,3] or None); ``keep`` is 1 where
-    a channel was not clamped to 0 and 0 where it was (multiply the colour gradient by it before ``sh_backward``)."""
+    a channel was not clamped to 0 and 0 where it was (multiply the colour gradient by it before ``sh_backward``).
+    ``out``: optional contiguous float32 [V,N,3] tensor to write the colours into (e.g. a communication buffer)."""
     lib = _lib.load()
     if not means3D.is_cuda:
         raise RuntimeError("sh_forward_views has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -50,7 +52,12 @@ def sh_forward_views(means3D: torch.Tensor, shs: torch.Tensor, campos_views: tor
     s = shs.detach().to(torch.float32).contiguous()
     cp = campos_views.detach().to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
     n, k, v = m.shape[0], s.shape[1], cp.shape[0]
-    colors = torch.empty(v, n, 3, dtype=torch.float32, device=dev)
+    if out is not None:
+        if out.dtype is not torch.float32 or not out.is_contiguous() or tuple(out.shape) != (v, n, 3) or out.device != dev:
+            raise RuntimeError("out must be a contiguous float32 [V,N,3] tensor on the splats' device")
+        colors = out
+    else:
+        colors = torch.empty(v, n, 3, dtype=torch.float32, device=dev)
     keep = torch.empty(v, n, 3, dtype=torch.float32, device=dev) if want_keep else None
     with torch.cuda.device(dev):
         _lib.check(lib.sr_sh_forward_views(n, k, int(sh_degree), v, _p(m), _p(s), _p(cp), _p(colors), _p(keep), _stream(dev)))

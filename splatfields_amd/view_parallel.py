@@ -126,7 +126,7 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
         if params[k].grad is None:
             params[k].grad = torch.zeros_like(params[k])
     dcol_local = dcol_views[0][None] if len(dcol_views) == 1 else torch.stack(dcol_views)
-    campos_all = torch.stack([c.camera_center.to(device=dev, dtype=torch.float32).reshape(3) for c in cams])
+    campos_all = _campos_of(cams, dev)
     if world > 1:
         gathered = torch.empty(world, len(mine), n, 3, dtype=torch.float32, device=dev)
         # the collectives run in issue order on RCCL's stream: the all-gather first (the SH rebuild needs it), then ONE
@@ -145,6 +145,25 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
             params[k].grad = v
     else:
         params["shs"].grad = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
+
+
+_CAMPOS_CACHE: dict = {}
+
+
+def _campos_of(cams: Sequence, dev) -> torch.Tensor:
+    """[V,3] camera centres of a view list; the same cameras come back every step, so the stacked tensor is kept (the entry
+    holds the source tensors, so their ids cannot be recycled, and is rebuilt if one was modified in place)."""
+    src = tuple(c.camera_center for c in cams)
+    key = (tuple(id(t) for t in src), str(dev))
+    versions = tuple(t._version for t in src)
+    hit = _CAMPOS_CACHE.get(key)
+    if hit is not None and hit[1] == versions and all(a is b for a, b in zip(hit[2], src)):
+        return hit[0]
+    out = torch.stack([t.to(device=dev, dtype=torch.float32).reshape(3) for t in src])
+    if len(_CAMPOS_CACHE) > 256:
+        _CAMPOS_CACHE.clear()
+    _CAMPOS_CACHE[key] = (out, versions, src)
+    return out
 
 
 def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
@@ -199,16 +218,18 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
     n_own = hi - lo
     # views in (destination rank d, slot) order: rank d renders views d, d + world, ...
     order = [d + sl * world for d in range(world) for sl in range(k)]
-    campos = torch.stack([cams[vi].camera_center.to(device=dev, dtype=torch.float32).reshape(3) for vi in order])
+    campos = _campos_of([cams[vi] for vi in order], dev)
     m_own, sh_own = means3D.detach()[lo:hi], shs.detach()[lo:hi]
 
     # 1. colours of my shard for every view -> the ranks that render them
     send = torch.zeros(world, k, shard, 3, dtype=torch.float32, device=dev) if n_own < shard else \
         torch.empty(world, k, shard, 3, dtype=torch.float32, device=dev)
     keep = None
-    if n_own > 0:
+    if n_own == shard:   # the usual case: the kernel writes straight into the communication buffer
+        _, keep = shmod.sh_forward_views(m_own, sh_own, campos, sh_degree, out=send.view(V, shard, 3))
+    elif n_own > 0:      # short last shard: pad rows stay zero
         col_own, keep = shmod.sh_forward_views(m_own, sh_own, campos, sh_degree)     # [V, n_own, 3] each
-        send.view(V, shard, 3)[:, :n_own].copy_(col_own) if n_own < shard else send.view(V, shard, 3).copy_(col_own)
+        send.view(V, shard, 3)[:, :n_own].copy_(col_own)
     if world > 1:
         recv = torch.empty_like(send)
         _all_to_all(recv, send, group)
