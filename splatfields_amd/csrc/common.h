@@ -36,7 +36,7 @@ constexpr uint8_t kFlagClampR = 1, kFlagClampG = 2, kFlagClampB = 4, kFlagClampT
 struct Geom {
     // [N][4] one 64-byte, 64-byte-aligned record per splat, so a gather touches exactly one cache line:
     //   q0 = (pix.x, pix.y, tau = 2 ln(255 o) * log2(e) [support: d^T Q' d <= tau; < 0: never visible], view depth)
-    //   q1 = (p, s, q, -log2 o): completed-square factors of Q' = conic * log2(e), see pair_alpha_unclamped()      q2 = (r, g, b, unused)
+    //   q1 = (p, s, q, -log2 o): completed-square factors of Q' = conic * log2(e), see pair_alpha_unclamped()      q2 = (r, g, b, view depth)
     //   q3 = (bits: tile rect xmin | ymin << 16, bits: rect width, unused, unused)  -- instance index of (splat, tile)
     float4* rec;
     ushort4* rect;       // [N] tile rect (xmin, ymin, xmax, ymax), max exclusive

@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                     const float inv_c = 1.0f / c;
                     rec[1] = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
                                          opac > 0.0f ? -__log2f(opac) : 0.0f);
-                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);  // the blend kernels read the depth with the colour: one 16-byte LDS read
                     // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
                     // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
                     // partial write, which costs more than the 16 bytes (0.087 -> 0.078 ms for this kernel).

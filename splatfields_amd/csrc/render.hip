@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     const uint64_t blendm = hitm ^ stopm;  // stop implies hit
                     livem &= ~stopm;
                     const float w = mask_select(blendm, alpha * T, 0.0f);
-                    Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r0.w, w, D);
+                    Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r2.w, w, D);
                     T = mask_select(blendm, test_T, T);
                     if (stopm != 0ull) last = mask_select(stopm, pos0 + (uint32_t)bit, last);  // rare: once per pixel at most
                 }
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         // The upstream gradient g is constant along the list, so the "colour behind" enters only through
                         // its dot product with g: ONE scalar recurrence (behind_g) instead of one per channel.
                         float cg = HAS_A ? gA : 0.0f;  // the alpha channel's "colour" is 1 for every splat
-                        if (HAS_D) cg = fmaf(r0.w, gD, cg);
+                        if (HAS_D) cg = fmaf(r2.w, gD, cg);
                         cg = fmaf(r2.z, gB, cg); cg = fmaf(r2.y, gG, cg); cg = fmaf(r2.x, gR, cg);
                         const float dLa = T * cg - inv_keep * behind_g;
                         behind_g = fmaf(wgt, cg, behind_g);
