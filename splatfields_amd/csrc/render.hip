@@ -18,7 +18,7 @@
 namespace sr {
 
 constexpr int kFwdBatch = 256;
-constexpr int kBwdBatch = 128;  // 64 and 256 measured slower (0.541 / 0.680 vs 0.528 ms)
+constexpr int kBwdBatch = 128;  // 64 / 96 / 192 / 256 all measured slower (tried and rejected)
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
