@@ -248,7 +248,11 @@ def main():
                    "visible_splats": vis, "tile_instances": R, "inputs": args.inputs, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": dom_bw / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
-                     "avg_launch_ms": stage_ms[dom]},
+                     "avg_launch_ms": stage_ms[dom],
+                     "note": ("the two blend kernels are VALU-issue-bound, not HBM-bound (rocprofv3 SQ counters in profiles/: 4.6-4.9 "
+                              "launch cycles per wave-level VALU instruction per SIMD); `traffic` is L2<->fabric bytes incl. requests "
+                              "served by the 256 MB infinity cache; the HBM-bound stages are preprocess / preprocess_backward "
+                              "(DESIGN.md section 5)")},
         "roofline_pipeline": {"b_alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                               "frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
                               "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
