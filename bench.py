@@ -257,6 +257,8 @@ def main():
                               "frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
                               "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
         "stage_ms": stage_ms,
+        # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
+        "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }
     if rank == 0 and world == 1 and args.cpu_baseline != "none":
         from oracle.cpu_baseline import run_cpu_baseline  # the oracle is used here only as the timed CPU baseline
