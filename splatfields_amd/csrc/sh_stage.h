@@ -19,7 +19,7 @@ __device__ __forceinline__ void stage_sh_in(float4* s_sh, const float* shs, size
 #pragma unroll
     for (int it = 0; it < 12; ++it) {
         const int i = it * kBlock + (int)threadIdx.x;
-        tmp[it] = i < total ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tmp[it] = i < total ? load_stream(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < 12; ++it) {
@@ -54,7 +54,7 @@ __device__ __forceinline__ void stage_in_linear(float* lds, const float* src, in
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int f0 = 4 * (it * kBlock + (int)threadIdx.x);
-        if (f0 + 3 < total_f) tmp[it] = *reinterpret_cast<const float4*>(src + f0);
+        if (f0 + 3 < total_f) tmp[it] = load_stream(reinterpret_cast<const float4*>(src + f0));
         else  // last, partial float4 of the array: never read past its end
             tmp[it] = make_float4(f0 < total_f ? src[f0] : 0.f, f0 + 1 < total_f ? src[f0 + 1] : 0.f,
                                   f0 + 2 < total_f ? src[f0 + 2] : 0.f, 0.f);
