@@ -35,7 +35,7 @@ __device__ __forceinline__ void stage_sh_out(const float4* s_sh, float* dst_base
     for (int it = 0; it < 12; ++it) {
         const int i = it * kBlock + (int)threadIdx.x;
         const int sp = i / 12;
-        if (i < total) dst[i] = s_sh[sp * kShRowF4 + (i - sp * 12)];
+        if (i < total) store_stream(dst + i, s_sh[sp * kShRowF4 + (i - sp * 12)]);
     }
 }
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ void stage_out_linear(const float* lds, float* dst, i
         const int f0 = 4 * (it * kBlock + (int)threadIdx.x);
         if (f0 >= total_f) continue;
         const float4 v = *reinterpret_cast<const float4*>(lds + f0);
-        if (f0 + 3 < total_f) *reinterpret_cast<float4*>(dst + f0) = v;
+        if (f0 + 3 < total_f) store_stream(reinterpret_cast<float4*>(dst + f0), v);
         else {
             dst[f0] = v.x;
             if (f0 + 1 < total_f) dst[f0 + 1] = v.y;
