@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                             }
                             // two 16-byte stores + one 4-byte store per splat (three coalesced streams)
                             float4* jq = reinterpret_cast<float4*>(g.dcol_ddir);
-                            jq[idx] = make_float4(jac[0], jac[1], jac[2], jac[3]);
-                            jq[(size_t)s.N + idx] = make_float4(jac[4], jac[5], jac[6], jac[7]);
+                            store_stream(jq + idx, make_float4(jac[0], jac[1], jac[2], jac[3]));   // whole lines, read next in the backward
+                            store_stream(jq + (size_t)s.N + idx, make_float4(jac[4], jac[5], jac[6], jac[7]));
                             g.dcol_ddir[(size_t)8 * s.N + idx] = jac[8];
                         }
                         rgb.x += 0.5f; rgb.y += 0.5f; rgb.z += 0.5f;
