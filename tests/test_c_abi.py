@@ -89,3 +89,14 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".h")):
                     src = open(os.path.join(dirpath, f)).read()
                     assert "import oracle" not in src and "from oracle" not in src and "raster_ref" not in src, f
+
+
+def test_header_constants_match_the_binding():
+    """#define values of include/splatraster.h == the Python binding's constants."""
+    from splatfields_amd import _lib
+    text = open(os.path.join(ROOT, "include", "splatraster.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+(SR_[A-Z_]+)\s+(\d+)\b", text, re.M)}
+    assert defs["SR_NEED_CAPACITY"] == _lib.SR_NEED_CAPACITY
+    assert (defs["SR_RAW_SCALES"], defs["SR_RAW_OPACITY"], defs["SR_RAW_ROTATIONS"], defs["SR_FORWARD_ONLY"]) == \
+        (_lib.SR_RAW_SCALES, _lib.SR_RAW_OPACITY, _lib.SR_RAW_ROTATIONS, _lib.SR_FORWARD_ONLY)
+    assert defs["SR_PROFILE_STAGES"] == _lib.PROFILE_STAGES
