@@ -147,11 +147,12 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         // classes; the order inside a class is arbitrary (it only affects scheduling, never results).
         __shared__ uint32_t s_hist[256];
         const uint32_t longest = max(s_wave[0], 1u);
+        const float to_class = 255.0f / (float)longest;   // class = 255 - floor(255 len / longest), in float: no 64-bit division
         if (tid < 256) s_hist[tid] = 0u;
         __syncthreads();
         for (int i = tid; i < n; i += 1024) {
             const uint32_t len = dst[i + 1] - dst[i];   // written by this workgroup above (barriers in between)
-            atomicAdd(&s_hist[255u - (uint32_t)(((uint64_t)len * 255u) / longest)], 1u);
+            atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u);
         }
         __syncthreads();
         if (w == 0) {  // exclusive prefix over the 256 classes: 4 per lane
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         __syncthreads();
         for (int i = tid; i < n; i += 1024) {
             const uint32_t len = dst[i + 1] - dst[i];
-            g.tile_order[atomicAdd(&s_hist[255u - (uint32_t)(((uint64_t)len * 255u) / longest)], 1u)] = (uint32_t)i;
+            g.tile_order[atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u)] = (uint32_t)i;
         }
     }
 }
