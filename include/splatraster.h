@@ -187,6 +187,15 @@ int sr_sh_backward(int n_splats, int sh_coeffs, int sh_degree, int n_views, cons
 size_t sr_knn_workspace_bytes(int n_points);
 int sr_knn3_mean_dist2(int n_points, const float* points, float* mean_dist2, void* workspace, void* hip_stream);
 
+/* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
+ * (`instances` = the capacity the binning buffer was carved for):
+ *   out[0]  geom:    tile_start  uint32[tiles + 1]   first list entry of every 16x16 tile (row-major tiles)
+ *   out[1]  binning: sorted_id   uint32[instances]   splat index of every list entry, per tile front to back
+ *   out[2]  geom:    total       uint32[4]           [0] = tile-splat instances
+ *   out[3]  geom:    offsets     uint32[N]           first gradient slot of every splat
+ * The per-tile lists are the counterpart of [EXT]'s sorted point_list + ranges (binningBuffer / imgBuffer). */
+int sr_debug_layout(int n_splats, int height, int width, long long instances, size_t* out4);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; off by default, adds two event records per launch when on).
  * sr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch counts

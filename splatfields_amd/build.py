@@ -9,8 +9,8 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libsplatraster.so"
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "knn.hip", "sh.hip"]
-HEADERS = ["common.h", "kernels.h", "expand.h", "sh_stage.h", "../../include/splatraster.h"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "blend_bwd.hip", "knn.hip", "sh.hip"]
+HEADERS = ["common.h", "kernels.h", "expand.h", "sh_stage.h", "quadmask.h", "../../include/splatraster.h"]
 
 
 def _hipcc() -> str:
@@ -27,20 +27,27 @@ def is_stale() -> bool:
     return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 ... -> splatfields_amd/libsplatraster.so (cross-compiles without a GPU)."""
-    if not force and not is_stale():
+def build_library(force: bool = False, verbose: bool = False, out: Path = None, defines=()) -> Path:
+    """hipcc --offload-arch=gfx950 ... -> splatfields_amd/libsplatraster.so (cross-compiles without a GPU).
+
+    `out` / `defines`: an experimental variant of the same ABI (A/B timing through SPLATRASTER_LIB, tools/ab.sh)."""
+    if out is None and not force and not is_stale():
         return LIB_PATH
+    target = Path(out) if out is not None else LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
            # the SLP vectoriser pairs fp32 adds into v_pk_add_f32, which blocks DPP fusion (v_add_f32_dpp) in the
            # wave reductions and costs extra v_mov shuffles in the VALU-bound blend loops
-           "-fno-slp-vectorize",
-           "-o", str(LIB_PATH)] + [str(CSRC / f) for f in SOURCES]
+           "-fno-slp-vectorize"] + [f"-D{d}" for d in defines] + [
+           "-o", str(target)] + [str(CSRC / f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=str(CSRC))
-    return LIB_PATH
+    return target
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1:   # python -m splatfields_amd.build OUT.so [DEFINE ...]
+        print(build_library(force=True, verbose=True, out=Path(sys.argv[1]).resolve(), defines=sys.argv[2:]))
+    else:
+        print(build_library(force=True, verbose=True))

@@ -1,6 +1,7 @@
 // C ABI of libsplatraster.so (see include/splatraster.h for what each entry replaces).
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -238,7 +239,13 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     uint8_t* reached = static_cast<uint8_t*>(scratch);
     float* slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + sr::align_up(n_inst, 256));
     SR_TRY(check_hip(hipMemsetAsync(reached, 0, n_inst, st), "clear reached flags"));
-    { StageTimer t_(5, st); sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st); }
+    {
+        StageTimer t_(5, st);
+        const char* sel = getenv("SPLATRASTER_BWD");   // "wave": round 1's pixel-per-lane kernel (kept for A/B measurements)
+        const bool wave_kernel = sel && std::string(sel) == "wave";
+        if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
+        else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
+    }
     SR_TRY(after_launch(view, st, "render_backward"));
     sr::GradsK gr;
     gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
@@ -298,6 +305,19 @@ int sr_knn3_mean_dist2(int n, const float* points, float* mean_dist2, void* work
     if (n < 0 || (n > 0 && (!points || !mean_dist2 || !workspace))) return fail("bad arguments to sr_knn3_mean_dist2");
     sr::launch_knn3(n, points, mean_dist2, workspace, static_cast<hipStream_t>(hip_stream));
     return check_hip(hipGetLastError(), "knn3");
+}
+
+int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {
+    if (!out4 || n < 0 || h <= 0 || w <= 0 || instances < 0) return fail("bad arguments to sr_debug_layout");
+    sr::Geom g; sr::Binning b;
+    char* const origin = reinterpret_cast<char*>(4096);   // carve relative to a non-null base: only differences are used
+    sr::carve_geom(origin, n, h, w, &g);
+    sr::carve_binning(origin, instances, &b);
+    out4[0] = (size_t)(reinterpret_cast<char*>(g.tile_start) - origin);
+    out4[1] = (size_t)(reinterpret_cast<char*>(b.sorted_id) - origin);
+    out4[2] = (size_t)(reinterpret_cast<char*>(g.total) - origin);
+    out4[3] = (size_t)(reinterpret_cast<char*>(g.offsets) - origin);
+    return 0;
 }
 
 int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }

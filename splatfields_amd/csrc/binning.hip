@@ -18,6 +18,17 @@
 
 namespace sr {
 
+// Kernels whose dynamic LDS can exceed the 64 KiB default limit need the attribute raised once per device (it belongs to
+// the device's copy of the kernel).  `slot` = a small fixed id per kernel.
+static void allow_dynamic_lds(const void* kernel, int slot, int bytes) {
+    static bool done[8][64] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[slot][dev]) return;
+    hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 64) done[slot][dev] = true;
+}
+
 // ---- atomic-free per-tile counts: count matrix [chunk][tile] built with LDS atomics only ----------
 // A chunk is a run of consecutive 256-splat sub-batches owned by one workgroup.  The workgroup keeps a
 // histogram over ALL tiles in LDS (800x800 -> 2500 counters = 10 KiB of the CU's 160 KiB), walks its
@@ -83,6 +94,8 @@ __global__ void __launch_bounds__(kBlock) k_colscan_local(const Geom g, const Ch
 void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
     if (!use_count_matrix(v) || N <= 0) return;
     const Chunking ch = make_chunking(N, v.gx * v.gy);
+    // images close to kMaxMatrixTiles tiles: 64 KiB of dynamic histogram + 3 KiB static exceeds the 64 KiB default limit
+    allow_dynamic_lds(reinterpret_cast<const void*>(&k_count_tiles), 0, (int)(sizeof(uint32_t) * kMaxMatrixTiles));
     hipLaunchKernelGGL(k_count_tiles, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, ch);
     hipLaunchKernelGGL(k_colscan_local, dim3(ch.tiles_padded / 64, ch.segments), dim3(kBlock), 0, st, g, ch);
 }
@@ -229,6 +242,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st) {
     if (N <= 0) return;
     const Chunking ch = make_chunking(N, v.gx * v.gy);
+    allow_dynamic_lds(reinterpret_cast<const void*>(&k_emit<true>), 1, (int)(sizeof(uint32_t) * kMaxMatrixTiles));   // see launch_count_tiles
     if (use_count_matrix(v))
         hipLaunchKernelGGL(k_emit<true>, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, b, ch);
     else
@@ -501,15 +515,9 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     if (max_len >= 0 && max_len <= 1024) return;
     hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 2048) return;
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the kernel
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(4096, 1024));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(8192, 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), 2, (int)lds(4096, 1024));
+    allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), 3, (int)lds(8192, 1024));
+    allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), 4, (int)lds(8192, 1024));
     hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
     // dense scenes put many tiles in this class too: one workgroup per tile (the launch is skipped when no list is this long)

@@ -37,6 +37,10 @@ void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, cons
 void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* slots, uint8_t* reached, hipStream_t st);
+// blend_bwd.hip
+void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+                                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                                 float* slots, uint8_t* reached, hipStream_t st);
 
 // knn.hip
 size_t knn_workspace_bytes(int n);
