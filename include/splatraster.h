@@ -196,6 +196,12 @@ int sr_knn3_mean_dist2(int n_points, const float* points, float* mean_dist2, voi
  * The per-tile lists are the counterpart of [EXT]'s sorted point_list + ranges (binningBuffer / imgBuffer). */
 int sr_debug_layout(int n_splats, int height, int width, long long instances, size_t* out4);
 
+/* Work counters of the backward blend, accumulated over the sr_backward calls of a library built with -DSR_BWD_STATS
+ * (bench.py's pairs_evaluated / pairs_blended; the product build leaves them out and returns zeros):
+ * out8 = { list entries replayed, (4x4 quad, entry) pairs, 16-entry buckets, (pixel, entry) pairs evaluated,
+ *          pairs blended, list chunks, 0, 0 }.  Synchronises the device; reset != 0 clears the counters afterwards. */
+int sr_debug_backward_stats(unsigned long long* out8, int reset);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; off by default, adds two event records per launch when on).
  * sr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch counts

@@ -320,6 +320,12 @@ int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {
     return 0;
 }
 
+int sr_debug_backward_stats(unsigned long long* out8, int reset) {
+    if (!out8) return fail("null pointer in sr_debug_backward_stats");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("sr_debug_backward_stats: device synchronisation failed");
+    return sr::backward_stats(out8, reset) ? fail("sr_debug_backward_stats: counter copy failed") : 0;
+}
+
 int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 
 int sr_profile_collect(double* ms_sum, long long* launches) {

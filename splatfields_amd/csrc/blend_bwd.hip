@@ -32,19 +32,27 @@ namespace sr {
 namespace {
 
 constexpr int kBucket = 16;                 // list entries per bucket = N of the MFMA
-constexpr int kBlkEntries = 64;             // list entries tested by one wavefront pass ("block")
-#ifndef SR_BWD_MAXE
-#define SR_BWD_MAXE 2
-#endif
-constexpr int kMaxE = SR_BWD_MAXE;          // blocks per wavefront per chunk (chunk <= 256 * kMaxE list entries)
-constexpr int kMaxBlocks = 4 * kMaxE;
+constexpr int kBlkEntries = 32;             // granularity of a chunk of the tile list ("block" = half a wavefront's entries)
+constexpr int kBlocks = 8;                  // a chunk = up to 8 blocks = one list entry per thread
 #ifndef SR_BWD_CAP
-#define SR_BWD_CAP 1024
+#define SR_BWD_CAP 880
 #endif
-constexpr int kCap = SR_BWD_CAP;            // (quad, entry) slots per chunk; one block can need 64 x 16 = 1024
-static_assert(kCap >= 1024 && kCap % 16 == 0, "one block must always fit");
+// (quad, entry) slots per chunk; one block can need 32 x 16 = 512.  880 slots x 48 B + 11 KB of tables = 53 KB of LDS:
+// three workgroups per CU (160 KB)
+constexpr int kCap = SR_BWD_CAP;
+static_assert(kCap >= kBlkEntries * 16 && kCap % 16 == 0, "one block must always fit");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef SR_BWD_STATS
+// diagnostic build only (bench.py's pairs_evaluated / pairs_blended figures): [0] list entries tested, [1] (quad, entry)
+// pairs, [2] buckets, [3] (pixel, entry) pairs evaluated, [4] pairs blended (alpha >= 1/255 and not behind the pixel's
+// last contributor), [5] chunks
+__device__ unsigned long long g_bwd_stats[8];
+#define SR_STAT_ADD(i, x) atomicAdd(&g_bwd_stats[i], (unsigned long long)(x))
+#else
+#define SR_STAT_ADD(i, x) do {} while (0)
+#endif
 
 // DPP controls: row_shr:n = 0x110 + n (lane l reads lane l - n of its row of 16), row_mirror = 0x140, row_ror:n = 0x120 + n
 constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118, kMirror = 0x140;
@@ -108,7 +116,76 @@ __device__ __forceinline__ uint32_t row_scan_add_u32(uint32_t x) {
 
 }  // namespace
 
-__global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im,
+// One list entry as the build phase holds it (one per thread and chunk).
+struct BwdEntry {
+    int pos;            // list position (descending with the thread index), < 0: none
+    float4 r0, r1, r2;  // record quarters: (cx, cy, tau2, depth) (p, s, q, -log2 o) (r, g, b, depth)
+    uint32_t rect_xy, rect_w, first;   // tile rect origin / width of the splat, its first gradient slot
+};
+
+__device__ __forceinline__ BwdEntry load_entry(const Geom& g, int pos, uint32_t id) {
+    BwdEntry e;
+    e.pos = pos;
+    e.r0 = e.r1 = e.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    e.rect_xy = e.rect_w = e.first = 0u;
+    if (pos >= 0) {
+        const float4* rec = g.rec + 4 * (size_t)id;
+        e.r0 = rec[0]; e.r1 = rec[1]; e.r2 = rec[2];
+        const float4 r3 = rec[3];
+        e.rect_xy = __float_as_uint(r3.x); e.rect_w = __float_as_uint(r3.y);
+        e.first = g.offsets[id];
+    }
+    return e;
+}
+
+// Per-quad constants of the replay (pixel row k of the quad, pixel columns t = 0..3).
+struct QuadCtx {
+    float pxf[4], gR[4], gG[4], gB[4], gD[4], gA[4], A1[4], A2[4];
+    int last[4];
+    float pyf;
+};
+
+// One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
+// the "colour behind . g" of every pixel from bucket to bucket (valid in lane 15 of each row).
+__device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0, const float4 e1, const float4 e2, const int pos,
+                                              float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
+    const float dy = e0.y - c.pyf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float dx = e0.x - c.pxf[t];
+        const float oG = pair_alpha_unclamped(dx, dy, e1);   // opacity * G: the forward's instruction sequence
+        const bool hit = (oG >= kAlphaMin) && (pos < c.last[t]);
+        const float oGc = hit ? oG : 0.0f;                   // everyone else: alpha = G = 0, transparent to the scans
+#ifdef SR_BWD_STATS
+        { const int nh = __popcll(__builtin_amdgcn_ballot_w64(hit)); if (lane == 0) SR_STAT_ADD(4, nh); }
+#endif
+        const float alpha = __builtin_amdgcn_fmed3f(oGc, 0.0f, kAlphaMax);
+        const float ginv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
+        const float T = row_scan_mul(shift_in_carry(ST[t], ginv)) * ginv;
+        ST[t] = T;   // lane 15: behind the next bucket
+        const float wgt = alpha * T;
+        float cgv = c.gA[t];   // the alpha channel's "colour" is 1 for every splat
+        cgv = fmaf(e2.w, c.gD[t], cgv); cgv = fmaf(e2.z, c.gB[t], cgv); cgv = fmaf(e2.y, c.gG[t], cgv); cgv = fmaf(e2.x, c.gR[t], cgv);
+        const float z = wgt * cgv;
+        // (colour accumulated behind entry n, incl. background) . upstream gradient
+        const float behind = row_scan_add(shift_in_carry(SB[t], z));
+        SB[t] = behind + z;
+        // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
+        const float dLa = T * cgv - ginv * behind;
+        const float g1 = oGc * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
+        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A1[t], g1, D1, 0, 0, 0);
+        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A2[t], wgt, D2, 0, 0, 0);
+    }
+    (void)lane;
+}
+
+#ifdef SR_BWD_WPE
+#define SR_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SR_BWD_WPE, SR_BWD_WPE)))
+#else
+#define SR_BWD_ATTR
+#endif
+__global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_ddepth,
                                                                  const float* __restrict__ dL_dalpha,
@@ -116,12 +193,15 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
     // slot i: [3 i] = (cx, cy, list position, -) -> (M0, MX, MY, MXX); [3 i + 1] = (p, s, q, -log2 o) -> (MXY, MYY, dr, dg);
     //         [3 i + 2] = (r, g, b, depth) -> (db, dd, 0, 0)
     __shared__ float4 s_slot[kCap * 3];
-    __shared__ float4 s_pixA[256];              // per pixel of the tile: dL/d(r, g, b, depth)
-    __shared__ float4 s_pixB[256];              // (dL/dalpha, last contributor + 1 [int bits], T state, "behind . g" state)
-    __shared__ uint64_t s_mask[16][kMaxBlocks]; // [quad][block]: lanes of the block whose entry reaches the quad
-    __shared__ uint16_t s_bb[16][kMaxBlocks];   // slot of the first entry of (quad, block)
-    __shared__ uint32_t s_qlen[16], s_qbase[16], s_qlast[16];
-    __shared__ uint32_t s_ctl[2];               // blocks used by this chunk, (quad, entry) pairs in them
+    __shared__ float4 s_pixA[256];                   // per pixel of the tile: dL/d(r, g, b, depth)
+    __shared__ float4 s_pixB[256];                   // (dL/dalpha, last contributor + 1 [int bits], T state, "behind . g" state)
+    // the small tables are double-buffered by chunk parity: a wavefront may start testing the next chunk while others
+    // still combine the previous one
+    __shared__ uint32_t s_mask[2][16][kBlocks];      // [quad][block]: entries of the block that reach the quad
+    __shared__ uint16_t s_bb[2][16][kBlocks];        // slot of the first entry of (quad, block)
+    __shared__ uint32_t s_qlen[2][16], s_qbase[2][16];
+    __shared__ uint32_t s_qlast[16];
+    __shared__ uint32_t s_ticket[2];                 // next quad to replay in this chunk (wavefronts take quads as they get free)
 
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
@@ -149,6 +229,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
         s_pixA[threadIdx.x] = make_float4(gR, gG, gB, gD);
         s_pixB[threadIdx.x] = make_float4(gA, __uint_as_float(my_last), T_final, T_final * bg_dot);
         if (threadIdx.x < 16) s_qlast[threadIdx.x] = 0u;
+        if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
         __syncthreads();
         atomicMax(&s_qlast[(ly >> 2) * 4 + (lx >> 2)], my_last);   // LDS, integer: order-independent
         __syncthreads();
@@ -159,124 +240,127 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
     const int bmax = __builtin_amdgcn_readfirstlane((int)bmax_u);   // uniform by construction; tell the compiler
     qlast_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlast_min);
 
+    const int k = lane >> 4, nl = lane & 15;
+    const uint32_t lt_mask = (1u << (lane & 31)) - 1u;   // earlier entries of this thread's block
+    const int myblk = (int)threadIdx.x >> 5;
+    const int tid = (int)threadIdx.x;
+    const uint32_t* ids = b.sorted_id + start;
+
+    // first chunk's entries: requested before anything else of the loop needs them
+    int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
+    BwdEntry cur;
+    {
+        const int pos = hi - 1 - tid;
+        cur = load_entry(g, pos, pos >= 0 ? ids[pos] : 0u);
+    }
+
     float4* slot4 = reinterpret_cast<float4*>(slots);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // List entries behind every pixel's last contributor receive no gradient.  With `flags` their slots are not written
     // at all and their `reached` byte stays 0 (the buffer is cleared before the launch); otherwise they are zero-filled.
     const bool flags = use_reached_flags(g.total);
     if (!flags) {
-        for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
-            const uint32_t id = b.sorted_id[start + i];
+        for (int i = bmax + tid; i < n; i += kBlock) {
+            const uint32_t id = ids[i];
             const ushort4 rc = g.rect[id];
             const size_t inst = g.offsets[id] + (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
             slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
         }
     }
 
-    const int k = lane >> 4, nl = lane & 15;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-    int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
-    int E = 1;       // blocks per wavefront in the next chunk (adapted to the density of (quad, entry) pairs)
+    int par = 0;   // chunk parity: which copy of the small tables
     while (hi > 0) {
-        // ---------------- (A) test: which quads does each entry of the chunk reach? ----------------
-        uint32_t qm[kMaxE], inst_of[kMaxE];
-        int pos_of[kMaxE];
-        float4 r0_of[kMaxE], r1_of[kMaxE], r2_of[kMaxE];
+        // ---------------- (A) test: which quads does this thread's entry reach? ----------------
+        uint32_t qm = 0u, inst = 0u;
+        if (cur.pos >= 0) {
+            inst = cur.first + ((uint32_t)ty - (cur.rect_xy >> 16)) * cur.rect_w + ((uint32_t)tx - (cur.rect_xy & 0xffffu));
+            qm = sr_quad_mask(cur.r0.x, cur.r0.y, cur.r0.z, cur.r1.x, cur.r1.y, cur.r1.z, tx0f, ty0f);
+            if ((uint32_t)cur.pos >= qlast_min) {   // behind the last contributor of every pixel of some quad
 #pragma unroll
-        for (int e = 0; e < kMaxE; ++e) {
-            qm[e] = 0u; inst_of[e] = 0u; pos_of[e] = -1;
-            r0_of[e] = zero4; r1_of[e] = zero4; r2_of[e] = zero4;
-            if (e < E) {
-                const int blk = e * 4 + wave;
-                const int pos = hi - 1 - (blk * kBlkEntries + lane);   // descending list position
-                pos_of[e] = pos;
-                if (pos >= 0) {
-                    const uint32_t id = b.sorted_id[start + (uint32_t)pos];
-                    const float4* rec = g.rec + 4 * (size_t)id;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                    const uint32_t first = g.offsets[id];
-                    const uint32_t xy = __float_as_uint(r3.x), rw = __float_as_uint(r3.y);
-                    inst_of[e] = first + ((uint32_t)ty - (xy >> 16)) * rw + ((uint32_t)tx - (xy & 0xffffu));
-                    r0_of[e] = r0; r1_of[e] = r1; r2_of[e] = r2;
-                    uint32_t m = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
-                    if ((uint32_t)pos >= qlast_min) {   // behind the last contributor of every pixel of some quad
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) if ((uint32_t)pos >= s_qlast[q]) m &= ~(1u << q);
-                    }
-                    qm[e] = m;
-                }
-                // one ballot per quad; lane q (< 16) collects quad q's mask
-                uint32_t mlo = 0u, mhi = 0u;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint64_t bal = __builtin_amdgcn_ballot_w64(((qm[e] >> q) & 1u) != 0u);
-                    const bool mine = lane == q;
-                    mlo = mine ? (uint32_t)bal : mlo;
-                    mhi = mine ? (uint32_t)(bal >> 32) : mhi;
-                }
-                if (lane < 16) s_mask[lane][blk] = ((uint64_t)mhi << 32) | mlo;
+                for (int q = 0; q < 16; ++q) if ((uint32_t)cur.pos >= s_qlast[q]) qm &= ~(1u << q);
             }
         }
+        {   // one ballot per quad (its halves are the wavefront's two blocks); lane q (< 16) collects quad q's mask
+            uint32_t mlo = 0u, mhi = 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint64_t bal = __builtin_amdgcn_ballot_w64(((qm >> q) & 1u) != 0u);
+                const bool mine = lane == q;
+                mlo = mine ? (uint32_t)bal : mlo;
+                mhi = mine ? (uint32_t)(bal >> 32) : mhi;
+            }
+            if (lane < 16) { s_mask[par][lane][2 * wave] = mlo; s_mask[par][lane][2 * wave + 1] = mhi; }
+        }
         __syncthreads();
-        // ---------------- (B) slot assignment (first wavefront): longest prefix of blocks that fits ----------------
-        if (wave == 0) {
-            const int q = nl;   // the four rows of the wavefront compute the same thing
-            uint32_t len = 0u, used = 0u;
-            uint32_t first_of[kMaxBlocks];
+        // ---------------- (B) slot assignment: longest prefix of blocks that fits (every wavefront computes the same) --------
+        int used;
+        {
+            const int q = nl;   // the four rows of a wavefront compute the same thing, too
+            uint32_t len = 0u, used_v = 0u;
+            uint32_t first_of[kBlocks];
             bool open = true;
 #pragma unroll
-            for (int blk = 0; blk < kMaxBlocks; ++blk) {
+            for (int blk = 0; blk < kBlocks; ++blk) {
                 first_of[blk] = len;
-                if (blk < 4 * E && open) {
-                    const uint32_t c = (uint32_t)__popcll(s_mask[q][blk]);
-                    const uint32_t padded = (len + c + 15u) & ~15u;
-                    if (row_allsum_u32(padded) <= (uint32_t)kCap) { len += c; used = blk + 1; }
-                    else open = false;
-                }
+                const uint32_t c = (uint32_t)__popc(s_mask[par][q][blk]);
+                const uint32_t padded = (len + c + 15u) & ~15u;
+                const bool fits = row_allsum_u32(padded) <= (uint32_t)kCap;
+                if (open && fits) { len += c; used_v = blk + 1; } else open = false;
             }
             const uint32_t padded = (len + 15u) & ~15u;
             const uint32_t base = row_scan_add_u32(padded) - padded;
-            const uint32_t pairs = row_allsum_u32(len);
-            if (lane < 16) {
-                s_qlen[q] = len; s_qbase[q] = base;
+            if (lane < 16) {   // all four wavefronts write the same values; each reads back only its own writes
+                s_qlen[par][q] = len; s_qbase[par][q] = base;
 #pragma unroll
-                for (int blk = 0; blk < kMaxBlocks; ++blk) s_bb[q][blk] = (uint16_t)(base + first_of[blk]);
+                for (int blk = 0; blk < kBlocks; ++blk) s_bb[par][q][blk] = (uint16_t)(base + first_of[blk]);
             }
-            if (lane == 0) { s_ctl[0] = used; s_ctl[1] = pairs; }
+            used = __builtin_amdgcn_readfirstlane((int)used_v);
+            if (threadIdx.x == 0) s_ticket[par ^ 1] = 0u;   // every wavefront has left the previous chunk's replay
+#ifdef SR_BWD_STATS
+            { const uint32_t pairs = row_allsum_u32(len);
+              if (threadIdx.x == 0) { SR_STAT_ADD(0, min(hi, kBlkEntries * used)); SR_STAT_ADD(1, pairs); SR_STAT_ADD(5, 1); } }
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __syncthreads();
-        const int used = __builtin_amdgcn_readfirstlane((int)s_ctl[0]);
-        const uint32_t pairs = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ctl[1]);
+        // next chunk's entry of this thread: the splat index is requested now, its record after the scatter -- both
+        // latencies hide behind the replay
+        const int npos = hi - kBlkEntries * used - 1 - tid;
+        const uint32_t nid = npos >= 0 ? ids[npos] : 0u;
         // ---------------- (C) scatter the records into the quads' slot runs ----------------
-#pragma unroll
-        for (int e = 0; e < kMaxE; ++e) {
-            const int blk = e * 4 + wave;
-            if (e < E && blk < used) {
-                uint32_t m = qm[e];
-                while (m) {
-                    const int q = __builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t slot = (uint32_t)s_bb[q][blk] + (uint32_t)__popcll(s_mask[q][blk] & lt_mask);
-                    s_slot[3 * slot] = make_float4(r0_of[e].x, r0_of[e].y, __int_as_float(pos_of[e]), 0.f);
-                    s_slot[3 * slot + 1] = r1_of[e];
-                    s_slot[3 * slot + 2] = r2_of[e];
-                }
+        if (myblk < used) {
+            uint32_t m = qm;
+            while (m) {
+                const int q = __builtin_ctz(m);
+                m &= m - 1u;
+                const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
+                s_slot[3 * slot] = make_float4(cur.r0.x, cur.r0.y, __int_as_float(cur.pos), 0.f);
+                s_slot[3 * slot + 1] = cur.r1;
+                s_slot[3 * slot + 2] = cur.r2;
             }
         }
+        const BwdEntry nxt = load_entry(g, npos, nid);
         __syncthreads();
         // ---------------- (D) replay: each wavefront walks the buckets of its four quads ----------------
+#ifndef SR_BWD_SKIP_REPLAY
+        // Quads are handed out through an LDS ticket (which wavefront replays which quad does not reach the results: every
+        // quad's sums go to its own slots and are combined in a fixed order).  The next ticket is drawn one quad ahead.
+        uint32_t ticket = 0u;
+        if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            const int qy = j, qx = (wave - j) & 3;   // one quad per quad-row and quad-column: balances the wavefronts
-            const int q = qy * 4 + qx;
-            const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[q]);
+        for (;;) {
+            const int q = __builtin_amdgcn_readfirstlane((int)ticket);
+            if (q >= 16) break;
+            if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
+            const int qy = q >> 2, qx = q & 3;
+            const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[par][q]);
             if (len == 0) continue;
-            const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[q]);
+            const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[par][q]);
             const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
-            float pxf[4], gR[4], gG[4], gB[4], gD[4], gA[4], ST[4], SB[4], A1[4], A2[4];
-            int last[4];
-            const float pyf = ty0f + (float)(4 * qy + k);
+            QuadCtx c;
+            float ST[4], SB[4];
+            c.pyf = ty0f + (float)(4 * qy + k);
             const float Y = (float)(4 * qy + k) - 7.5f;
             // MFMA A operands: this lane supplies row m = lane & 15 of the 16 x 4 operand for pixel row k.
             // rows 0-5: pixel monomials 1, X, Y, X^2, XY, Y^2 = c0 + X (c1 + X c2); rows 6-9: dL/d(r, g, b, depth)
@@ -286,49 +370,54 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
             const float w6 = nl == 6 ? 1.0f : 0.0f, w7 = nl == 7 ? 1.0f : 0.0f, w8 = nl == 8 ? 1.0f : 0.0f, w9 = nl == 9 ? 1.0f : 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float4 a = s_pixA[prow + t], c = s_pixB[prow + t];
-                gR[t] = a.x; gG[t] = a.y; gB[t] = a.z; gD[t] = a.w;
-                gA[t] = c.x; last[t] = __float_as_int(c.y); ST[t] = c.z; SB[t] = c.w;
-                pxf[t] = tx0f + (float)(4 * qx + t);
+                const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
+                c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
+                c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
+                c.pxf[t] = tx0f + (float)(4 * qx + t);
                 const float X = (float)(4 * qx + t) - 7.5f;
-                A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
-                A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
+                c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
+                c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
             }
+            int i0 = 0;
+            // two buckets per iteration: independent except for the carries, so their instruction streams interleave
 #pragma unroll 1
-            for (int i0 = 0; i0 < len; i0 += kBucket) {
-                const int slot = base + i0 + nl;
-                const bool valid = i0 + nl < len;
-                float4 e0 = s_slot[3 * slot], e1 = s_slot[3 * slot + 1], e2 = s_slot[3 * slot + 2];
-                if (!valid) { e0 = zero4; e1 = make_float4(0.f, 0.f, 0.f, __builtin_inff()); e2 = zero4; }   // alpha = 0
-                const int pos = valid ? __float_as_int(e0.z) : 0x7fffffff;
-                const float dy = e0.y - pyf;
-                f32x4 D1 = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float dx = e0.x - pxf[t];
-                    const float oG = pair_alpha_unclamped(dx, dy, e1);   // opacity * G: the forward's instruction sequence
-                    const bool hit = (oG >= kAlphaMin) && (pos < last[t]);
-                    const float oGc = hit ? oG : 0.0f;                   // everyone else: alpha = G = 0, transparent to the scans
-                    const float alpha = __builtin_amdgcn_fmed3f(oGc, 0.0f, kAlphaMax);
-                    const float ginv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
-                    const float T = row_scan_mul(shift_in_carry(ST[t], ginv)) * ginv;
-                    ST[t] = T;   // lane 15: behind the next bucket
-                    const float wgt = alpha * T;
-                    float cgv = gA[t];   // the alpha channel's "colour" is 1 for every splat
-                    cgv = fmaf(e2.w, gD[t], cgv); cgv = fmaf(e2.z, gB[t], cgv); cgv = fmaf(e2.y, gG[t], cgv); cgv = fmaf(e2.x, gR[t], cgv);
-                    const float z = wgt * cgv;
-                    // (colour accumulated behind entry n, incl. background) . upstream gradient
-                    const float behind = row_scan_add(shift_in_carry(SB[t], z));
-                    SB[t] = behind + z;
-                    // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
-                    const float dLa = T * cgv - ginv * behind;
-                    const float g1 = oGc * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
-                    D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[t], g1, D1, 0, 0, 0);
-                    D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[t], wgt, D2, 0, 0, 0);
-                }
+            for (; i0 + kBucket < len; i0 += 2 * kBucket) {
+                const int sa = base + i0 + nl, sb = sa + kBucket;
+                const bool vb = i0 + kBucket + nl < len;   // bucket A is full
+                const float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
+                float4 b0 = s_slot[3 * sb], b1 = s_slot[3 * sb + 1], b2 = s_slot[3 * sb + 2];
+                const int pa = __float_as_int(a0.z), pb = vb ? __float_as_int(b0.z) : 0x7fffffff;
+                b1.w = vb ? b1.w : __builtin_inff();   // a lane without an entry: alpha = 0 (stale slot contents are finite or not -- only
+                b0.x = vb ? b0.x : 0.f; b0.y = vb ? b0.y : 0.f;   // the exponent offset decides; keep the rest finite)
+                b1.x = vb ? b1.x : 0.f; b1.y = vb ? b1.y : 0.f; b1.z = vb ? b1.z : 0.f;
+                b2.x = vb ? b2.x : 0.f; b2.y = vb ? b2.y : 0.f; b2.z = vb ? b2.z : 0.f; b2.w = vb ? b2.w : 0.f;
+                f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
+#ifdef SR_BWD_STATS
+                if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
+#endif
+                replay_bucket(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
+                replay_bucket(c, b0, b1, b2, pb, ST, SB, D1b, D2b, lane);
                 // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
-                if (k < 3) s_slot[3 * slot + k] = make_float4(D1[0] + D2[0], D1[1] + D2[1], D1[2] + D2[2], D1[3] + D2[3]);
+                if (k < 3) {
+                    s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
+                    s_slot[3 * sb + k] = make_float4(D1b[0] + D2b[0], D1b[1] + D2b[1], D1b[2] + D2b[2], D1b[3] + D2b[3]);
+                }
+            }
+            if (i0 < len) {   // a last single bucket
+                const int sa = base + i0 + nl;
+                const bool va = i0 + nl < len;
+                float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
+                const int pa = va ? __float_as_int(a0.z) : 0x7fffffff;
+                a1.w = va ? a1.w : __builtin_inff();
+                a0.x = va ? a0.x : 0.f; a0.y = va ? a0.y : 0.f;
+                a1.x = va ? a1.x : 0.f; a1.y = va ? a1.y : 0.f; a1.z = va ? a1.z : 0.f;
+                a2.x = va ? a2.x : 0.f; a2.y = va ? a2.y : 0.f; a2.z = va ? a2.z : 0.f; a2.w = va ? a2.w : 0.f;
+                f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a;
+#ifdef SR_BWD_STATS
+                if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
+#endif
+                replay_bucket(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
+                if (k < 3) s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
             }
             if (nl == 15) {
 #pragma unroll
@@ -338,43 +427,55 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
                 }
             }
         }
+#endif
         __syncthreads();
         // ---------------- (E) combine the quads' sums of every entry, shift the moments to the splat centre ----------------
-#pragma unroll
-        for (int e = 0; e < kMaxE; ++e) {
-            const int blk = e * 4 + wave;
-            if (e < E && blk < used && pos_of[e] >= 0) {
-                float4 s0 = zero4, s1 = zero4, s2 = zero4;
-                uint32_t m = qm[e];
-                while (m) {   // ascending quad index: fixed summation order
-                    const int q = __builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t slot = (uint32_t)s_bb[q][blk] + (uint32_t)__popcll(s_mask[q][blk] & lt_mask);
-                    const float4 a = s_slot[3 * slot], c = s_slot[3 * slot + 1], d = s_slot[3 * slot + 2];
-                    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-                    s1.x += c.x; s1.y += c.y; s1.z += c.z; s1.w += c.w;
-                    s2.x += d.x; s2.y += d.y;
-                }
-                // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
-                const float ox = r0_of[e].x - (tx0f + 7.5f), oy = r0_of[e].y - (ty0f + 7.5f);
-                const float M0 = s0.x, MX = s0.y, MY = s0.z, MXX = s0.w, MXY = s1.x, MYY = s1.y;
-                const float Sx = ox * M0 - MX, Sy = oy * M0 - MY;
-                const float Sxx = fmaf(ox, Sx - MX, MXX);               // ox^2 M0 - 2 ox MX + MXX
-                const float Syy = fmaf(oy, Sy - MY, MYY);
-                const float Sxy = fmaf(ox, Sy, MXY) - oy * MX;          // ox oy M0 - ox MY - oy MX + MXY
-                const size_t inst = inst_of[e];
-                slot4[inst * 3] = make_float4(M0, Sx, Sy, Sxx);
-                slot4[inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
-                slot4[inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
-                if (flags) reached[inst] = 1;
+        if (myblk < used && cur.pos >= 0) {
+            float4 s0 = zero4, s1 = zero4, s2 = zero4;
+            uint32_t m = qm;
+            while (m) {   // ascending quad index: fixed summation order
+                const int q = __builtin_ctz(m);
+                m &= m - 1u;
+                const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
+                const float4 a = s_slot[3 * slot], cc = s_slot[3 * slot + 1], d = s_slot[3 * slot + 2];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
+                s2.x += d.x; s2.y += d.y;
             }
+            // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
+            const float ox = cur.r0.x - (tx0f + 7.5f), oy = cur.r0.y - (ty0f + 7.5f);
+            const float M0 = s0.x, MX = s0.y, MY = s0.z, MXX = s0.w, MXY = s1.x, MYY = s1.y;
+            const float Sx = ox * M0 - MX, Sy = oy * M0 - MY;
+            const float Sxx = fmaf(ox, Sx - MX, MXX);               // ox^2 M0 - 2 ox MX + MXX
+            const float Syy = fmaf(oy, Sy - MY, MYY);
+            const float Sxy = fmaf(ox, Sy, MXY) - oy * MX;          // ox oy M0 - ox MY - oy MX + MXY
+            slot4[(size_t)inst * 3] = make_float4(M0, Sx, Sy, Sxx);
+            slot4[(size_t)inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
+            slot4[(size_t)inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
+            if (flags) reached[inst] = 1;
         }
-        __syncthreads();   // the slots and masks are reused by the next chunk
+        // no barrier here: the next chunk's (A) touches only the other copy of the small tables, and its scatter (C) comes
+        // after the barrier that follows (A)
         hi -= kBlkEntries * used;
-        // next chunk: as many blocks as fit at the density of (quad, entry) pairs just seen
-        const float per_block = fmaxf((float)pairs / (float)max(used, 1), 1.0f);
-        E = min(kMaxE, max(1, (int)(0.9f * (float)kCap / per_block) / 4));
+        cur = nxt;
+        par ^= 1;
     }
+}
+
+// diagnostic counters of the SR_BWD_STATS build (zeros otherwise); reset != 0 clears them after reading
+int backward_stats(unsigned long long* out8, int reset) {
+#ifdef SR_BWD_STATS
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+#else
+    for (int i = 0; i < 8; ++i) out8[i] = 0ull;
+    (void)reset;
+    return 0;
+#endif
 }
 
 void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,

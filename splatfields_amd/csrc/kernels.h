@@ -42,6 +42,8 @@ void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                  float* slots, uint8_t* reached, hipStream_t st);
 
+int backward_stats(unsigned long long* out8, int reset);
+
 // knn.hip
 size_t knn_workspace_bytes(int n);
 void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream_t st);
