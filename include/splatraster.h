@@ -198,9 +198,11 @@ int sr_debug_layout(int n_splats, int height, int width, long long instances, si
 
 /* Work counters of the backward blend, accumulated over the sr_backward calls of a library built with -DSR_BWD_STATS
  * (bench.py's pairs_evaluated / pairs_blended; the product build leaves them out and returns zeros):
- * out8 = { list entries replayed, (4x4 quad, entry) pairs, 16-entry buckets, (pixel, entry) pairs evaluated,
- *          pairs blended, list chunks, 0, 0 }.  Synchronises the device; reset != 0 clears the counters afterwards. */
-int sr_debug_backward_stats(unsigned long long* out8, int reset);
+ * out16 = { list entries replayed, (4x4 quad, entry) pairs, 16-entry buckets, (pixel, entry) pairs evaluated,
+ *           pairs blended, list chunks, 0, 0,  then 8 shader-clock totals (summed over wavefronts) of the kernel's phases:
+ *           preamble, test, barrier, slot assignment + scatter, barrier, replay, barrier, combine }.
+ * Synchronises the device; reset != 0 clears the counters afterwards. */
+int sr_debug_backward_stats(unsigned long long* out16, int reset);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; off by default, adds two event records per launch when on).

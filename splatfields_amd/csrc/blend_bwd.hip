@@ -48,14 +48,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // diagnostic build only (bench.py's pairs_evaluated / pairs_blended figures): [0] list entries tested, [1] (quad, entry)
 // pairs, [2] buckets, [3] (pixel, entry) pairs evaluated, [4] pairs blended (alpha >= 1/255 and not behind the pixel's
 // last contributor), [5] chunks
-__device__ unsigned long long g_bwd_stats[8];
+__device__ unsigned long long g_bwd_stats[16];   // [8..15]: shader-clock cycles per phase, summed over wavefronts
 #define SR_STAT_ADD(i, x) atomicAdd(&g_bwd_stats[i], (unsigned long long)(x))
+#define SR_PHASE(i) do { const long long now_ = clock64(); ph_[i] += now_ - t_; t_ = now_; } while (0)
 #else
 #define SR_STAT_ADD(i, x) do {} while (0)
+#define SR_PHASE(i) do {} while (0)
 #endif
 
-// DPP controls: row_shr:n = 0x110 + n (lane l reads lane l - n of its row of 16), row_mirror = 0x140, row_ror:n = 0x120 + n
-constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118, kMirror = 0x140;
+// DPP controls: row_shr:n = 0x110 + n (lane l reads lane l - n of its row of 16), row_shl:n = 0x100 + n, row_ror:n = 0x120 + n
+constexpr int kShr1 = 0x111, kShr2 = 0x112, kShr4 = 0x114, kShr8 = 0x118;
 
 // value of lane (l - shift) of the row; lanes without a source (and nothing else) keep `old`
 template <int CTRL> __device__ __forceinline__ float dpp_f(float old, float src) {
@@ -65,43 +67,63 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, false);
 }
 
+// Row scans in both directions.  UP: lane l accumulates lanes <= l (row_shr), the carry of the previous bucket sits in
+// lane 0's `old` slot; DOWN: lane l accumulates lanes >= l (row_shl), carry in lane 15.  Buckets alternate direction, so
+// the total a bucket leaves in its last lane is already where the next bucket's first entry picks it up: no lane
+// broadcast, no rotate.
+constexpr int kShl1 = 0x101, kShl2 = 0x102, kShl4 = 0x104, kShl8 = 0x108;
 #ifdef SR_BWD_SCAN_SHFL
 // reference implementation of the row scans (ds_bpermute): debugging aid, selected at build time
-__device__ __forceinline__ float row_scan_add(float x) {
+template <bool UP> __device__ __forceinline__ float row_scan_add(float x) {
     const int n = threadIdx.x & 15;
-    for (int d = 1; d < 16; d <<= 1) { const float y = __shfl_up(x, d, 16); if (n >= d) x += y; }
+    for (int d = 1; d < 16; d <<= 1) {
+        const float y = UP ? __shfl_up(x, d, 16) : __shfl_down(x, d, 16);
+        if (UP ? n >= d : n + d < 16) x += y;
+    }
     return x;
 }
-__device__ __forceinline__ float row_scan_mul(float x) {
+template <bool UP> __device__ __forceinline__ float row_scan_mul(float x) {
     const int n = threadIdx.x & 15;
-    for (int d = 1; d < 16; d <<= 1) { const float y = __shfl_up(x, d, 16); if (n >= d) x *= y; }
+    for (int d = 1; d < 16; d <<= 1) {
+        const float y = UP ? __shfl_up(x, d, 16) : __shfl_down(x, d, 16);
+        if (UP ? n >= d : n + d < 16) x *= y;
+    }
     return x;
 }
-// lane 0 of each row: `carry` of lane 15; lane l >= 1: v of lane l - 1
-__device__ __forceinline__ float shift_in_carry(float carry, float v) {
+// UP: lane 0 keeps `carry` (its own lane's value), lane l >= 1 gets v of lane l - 1; DOWN: mirrored
+template <bool UP> __device__ __forceinline__ float shift_in_carry(float carry, float v) {
     const int n = threadIdx.x & 15;
-    const float c = __shfl(carry, 15, 16), y = __shfl_up(v, 1, 16);
-    return n == 0 ? c : y;
+    const float y = UP ? __shfl_up(v, 1, 16) : __shfl_down(v, 1, 16);
+    return (UP ? n == 0 : n == 15) ? carry : y;
 }
 #else
 // inclusive prefix over each row of 16 lanes (Kogge-Stone, 4 DPP steps)
-__device__ __forceinline__ float row_scan_add(float x) {
-    x += dpp_f<kShr1>(0.f, x); x += dpp_f<kShr2>(0.f, x); x += dpp_f<kShr4>(0.f, x); x += dpp_f<kShr8>(0.f, x);
+template <bool UP> __device__ __forceinline__ float row_scan_add(float x) {
+    if (UP) { x += dpp_f<kShr1>(0.f, x); x += dpp_f<kShr2>(0.f, x); x += dpp_f<kShr4>(0.f, x); x += dpp_f<kShr8>(0.f, x); }
+    else { x += dpp_f<kShl1>(0.f, x); x += dpp_f<kShl2>(0.f, x); x += dpp_f<kShl4>(0.f, x); x += dpp_f<kShl8>(0.f, x); }
     return x;
 }
 // The product scan needs "lanes without a source keep their own value", i.e. v_mul_f32_dpp with the destination as
 // `old` operand; the compiler only fuses DPP moves whose fill value is 0 (it emits v_mov 1.0 + v_mov_dpp + v_mul, three
 // issue slots per level), so the four levels are written out.  s_nop 1 = the two wait states a DPP read needs after the
 // VALU write of its source (the hazard recogniser does not look inside inline assembly).
-__device__ __forceinline__ float row_scan_mul(float x) {
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+template <bool UP> __device__ __forceinline__ float row_scan_mul(float x) {
+    if (UP) {
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    } else {
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+        asm("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    }
     return x;
 }
-__device__ __forceinline__ float shift_in_carry(float carry, float v) {
-    return dpp_f<kShr1>(dpp_f<kMirror>(carry, carry), v);   // row_mirror: lane 0 <- lane 15
+// the neighbour's value; the first lane of the scan direction (no source) keeps its own `carry`
+template <bool UP> __device__ __forceinline__ float shift_in_carry(float carry, float v) {
+    return UP ? dpp_f<kShr1>(carry, v) : dpp_f<kShl1>(carry, v);
 }
 #endif
 
@@ -146,7 +168,9 @@ struct QuadCtx {
 };
 
 // One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
-// the "colour behind . g" of every pixel from bucket to bucket (valid in lane 15 of each row).
+// the "colour behind . g" of every pixel from bucket to bucket: an UP bucket (entries back to front in lanes 0..15) takes
+// them from lane 0 and leaves them in lane 15, a DOWN bucket (entries in lanes 15..0) the other way round.
+template <bool UP>
 __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0, const float4 e1, const float4 e2, const int pos,
                                               float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
     const float dy = e0.y - c.pyf;
@@ -162,14 +186,14 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0,
         const float alpha = __builtin_amdgcn_fmed3f(oGc, 0.0f, kAlphaMax);
         const float ginv = __builtin_amdgcn_rcpf(1.0f - alpha);
         // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
-        const float T = row_scan_mul(shift_in_carry(ST[t], ginv)) * ginv;
-        ST[t] = T;   // lane 15: behind the next bucket
+        const float T = row_scan_mul<UP>(shift_in_carry<UP>(ST[t], ginv)) * ginv;
+        ST[t] = T;   // last lane of the scan: behind the next bucket
         const float wgt = alpha * T;
         float cgv = c.gA[t];   // the alpha channel's "colour" is 1 for every splat
         cgv = fmaf(e2.w, c.gD[t], cgv); cgv = fmaf(e2.z, c.gB[t], cgv); cgv = fmaf(e2.y, c.gG[t], cgv); cgv = fmaf(e2.x, c.gR[t], cgv);
         const float z = wgt * cgv;
         // (colour accumulated behind entry n, incl. background) . upstream gradient
-        const float behind = row_scan_add(shift_in_carry(SB[t], z));
+        const float behind = row_scan_add<UP>(shift_in_carry<UP>(SB[t], z));
         SB[t] = behind + z;
         // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
         const float dLa = T * cgv - ginv * behind;
@@ -209,6 +233,13 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
     const int n = (int)(end - start);
     const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
+#ifdef SR_BWD_STATS
+    long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ = clock64();
+#endif
+
+    const int tid = (int)threadIdx.x;
+    const uint32_t* ids = b.sorted_id + start;
+    const bool flags = use_reached_flags(g.total);
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -243,8 +274,6 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
     const int k = lane >> 4, nl = lane & 15;
     const uint32_t lt_mask = (1u << (lane & 31)) - 1u;   // earlier entries of this thread's block
     const int myblk = (int)threadIdx.x >> 5;
-    const int tid = (int)threadIdx.x;
-    const uint32_t* ids = b.sorted_id + start;
 
     // first chunk's entries: requested before anything else of the loop needs them
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
@@ -258,7 +287,6 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // List entries behind every pixel's last contributor receive no gradient.  With `flags` their slots are not written
     // at all and their `reached` byte stays 0 (the buffer is cleared before the launch); otherwise they are zero-filled.
-    const bool flags = use_reached_flags(g.total);
     if (!flags) {
         for (int i = bmax + tid; i < n; i += kBlock) {
             const uint32_t id = ids[i];
@@ -269,6 +297,7 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
     }
 
     int par = 0;   // chunk parity: which copy of the small tables
+    SR_PHASE(0);   // preamble
     while (hi > 0) {
         // ---------------- (A) test: which quads does this thread's entry reach? ----------------
         uint32_t qm = 0u, inst = 0u;
@@ -291,7 +320,9 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
             }
             if (lane < 16) { s_mask[par][lane][2 * wave] = mlo; s_mask[par][lane][2 * wave + 1] = mhi; }
         }
+        SR_PHASE(1);   // (A) test + ballots
         __syncthreads();
+        SR_PHASE(2);   // barrier after (A)
         // ---------------- (B) slot assignment: longest prefix of blocks that fits (every wavefront computes the same) --------
         int used;
         {
@@ -341,7 +372,9 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
             }
         }
         const BwdEntry nxt = load_entry(g, npos, nid);
+        SR_PHASE(3);   // (B) + (C)
         __syncthreads();
+        SR_PHASE(4);   // barrier after (C)
         // ---------------- (D) replay: each wavefront walks the buckets of its four quads ----------------
 #ifndef SR_BWD_SKIP_REPLAY
         // Quads are handed out through an LDS ticket (which wavefront replays which quad does not reach the results: every
@@ -378,35 +411,42 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
                 c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
                 c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
             }
+            // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
+            // interleave.  The slots of the next iteration are read while this one computes.
+            const int last_bucket = ((len - 1) >> 4) << 4;   // first entry of the quad's last bucket
+            auto slot_of = [&](int i, bool up) { return base + min(i, last_bucket) + (up ? nl : 15 - nl); };
             int i0 = 0;
-            // two buckets per iteration: independent except for the carries, so their instruction streams interleave
+            int sa = slot_of(0, true), sb = slot_of(kBucket, false);
+            float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
+            float4 b0 = s_slot[3 * sb], b1 = s_slot[3 * sb + 1], b2 = s_slot[3 * sb + 2];
 #pragma unroll 1
             for (; i0 + kBucket < len; i0 += 2 * kBucket) {
-                const int sa = base + i0 + nl, sb = sa + kBucket;
-                const bool vb = i0 + kBucket + nl < len;   // bucket A is full
-                const float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
-                float4 b0 = s_slot[3 * sb], b1 = s_slot[3 * sb + 1], b2 = s_slot[3 * sb + 2];
+                const int sa_n = slot_of(i0 + 2 * kBucket, true), sb_n = slot_of(i0 + 3 * kBucket, false);
+                const float4 na0 = s_slot[3 * sa_n], na1 = s_slot[3 * sa_n + 1], na2 = s_slot[3 * sa_n + 2];
+                const float4 nb0 = s_slot[3 * sb_n], nb1 = s_slot[3 * sb_n + 1], nb2 = s_slot[3 * sb_n + 2];
+                const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
                 const int pa = __float_as_int(a0.z), pb = vb ? __float_as_int(b0.z) : 0x7fffffff;
-                b1.w = vb ? b1.w : __builtin_inff();   // a lane without an entry: alpha = 0 (stale slot contents are finite or not -- only
-                b0.x = vb ? b0.x : 0.f; b0.y = vb ? b0.y : 0.f;   // the exponent offset decides; keep the rest finite)
+                b1.w = vb ? b1.w : __builtin_inff();   // a lane without an entry: alpha = 0 (only the exponent offset decides;
+                b0.x = vb ? b0.x : 0.f; b0.y = vb ? b0.y : 0.f;   // the rest of the stale slot is kept finite)
                 b1.x = vb ? b1.x : 0.f; b1.y = vb ? b1.y : 0.f; b1.z = vb ? b1.z : 0.f;
                 b2.x = vb ? b2.x : 0.f; b2.y = vb ? b2.y : 0.f; b2.z = vb ? b2.z : 0.f; b2.w = vb ? b2.w : 0.f;
                 f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
 #ifdef SR_BWD_STATS
                 if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
 #endif
-                replay_bucket(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
-                replay_bucket(c, b0, b1, b2, pb, ST, SB, D1b, D2b, lane);
+                replay_bucket<true>(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
+                replay_bucket<false>(c, b0, b1, b2, pb, ST, SB, D1b, D2b, lane);
                 // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
                 if (k < 3) {
                     s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
-                    s_slot[3 * sb + k] = make_float4(D1b[0] + D2b[0], D1b[1] + D2b[1], D1b[2] + D2b[2], D1b[3] + D2b[3]);
+                    if (vb) s_slot[3 * sb + k] = make_float4(D1b[0] + D2b[0], D1b[1] + D2b[1], D1b[2] + D2b[2], D1b[3] + D2b[3]);
                 }
+                sa = sa_n; sb = sb_n;
+                a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
             }
-            if (i0 < len) {   // a last single bucket
-                const int sa = base + i0 + nl;
+            const bool tail = i0 < len;   // a last single bucket (UP): its carries end in lane 15, otherwise they are in lane 0
+            if (tail) {
                 const bool va = i0 + nl < len;
-                float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
                 const int pa = va ? __float_as_int(a0.z) : 0x7fffffff;
                 a1.w = va ? a1.w : __builtin_inff();
                 a0.x = va ? a0.x : 0.f; a0.y = va ? a0.y : 0.f;
@@ -416,10 +456,10 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
 #ifdef SR_BWD_STATS
                 if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
 #endif
-                replay_bucket(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
-                if (k < 3) s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
+                replay_bucket<true>(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
+                if (k < 3 && va) s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
             }
-            if (nl == 15) {
+            if (nl == (tail ? 15 : 0)) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     float* st = reinterpret_cast<float*>(&s_pixB[prow + t]);
@@ -428,7 +468,9 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
             }
         }
 #endif
+        SR_PHASE(5);   // (D) replay
         __syncthreads();
+        SR_PHASE(6);   // barrier after (D)
         // ---------------- (E) combine the quads' sums of every entry, shift the moments to the splat centre ----------------
         if (myblk < used && cur.pos >= 0) {
             float4 s0 = zero4, s1 = zero4, s2 = zero4;
@@ -459,20 +501,24 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
         hi -= kBlkEntries * used;
         cur = nxt;
         par ^= 1;
+        SR_PHASE(7);   // (E) combine
     }
+#ifdef SR_BWD_STATS
+    if (lane == 0) for (int i = 0; i < 8; ++i) SR_STAT_ADD(8 + i, ph_[i]);
+#endif
 }
 
 // diagnostic counters of the SR_BWD_STATS build (zeros otherwise); reset != 0 clears them after reading
-int backward_stats(unsigned long long* out8, int reset) {
+int backward_stats(unsigned long long* out8, int reset) {   // out8: 16 entries
 #ifdef SR_BWD_STATS
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bwd_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stats), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
 #else
-    for (int i = 0; i < 8; ++i) out8[i] = 0ull;
+    for (int i = 0; i < 16; ++i) out8[i] = 0ull;
     (void)reset;
     return 0;
 #endif

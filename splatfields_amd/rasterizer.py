@@ -16,6 +16,7 @@ There is no CPU path: tensors must live on a HIP device and the library must be 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -40,6 +41,25 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 LAST_INSTANCES = 0  # tile-splat instances of the most recent forward (diagnostics / bench)
+
+# Depth gradient switch.  The depth image is differentiable here: dL/ddepth reaches opacity, conic,
+# 2D mean and (through view-space z) means3D, which is what the depth losses of reference train.py:217-229 need and what the
+# pinned fork's name ("depth-diff-gaussian-rasterization") promises.  Its CUDA source is not available to confirm that its
+# backward consumes grad_depth, so the behaviour of a rasterizer with a non-differentiable depth output can be selected:
+# set_depth_gradient(False), or SPLATRASTER_DEPTH_GRAD=0 in the environment, drops dL/ddepth in the backward.
+_DEPTH_GRADIENT = os.environ.get("SPLATRASTER_DEPTH_GRAD", "1") not in ("0", "false", "False", "off")
+
+
+def set_depth_gradient(enabled: bool) -> bool:
+    """Propagate dL/ddepth through the rasterizer (default) or drop it.  Returns the previous setting."""
+    global _DEPTH_GRADIENT
+    prev, _DEPTH_GRADIENT = _DEPTH_GRADIENT, bool(enabled)
+    return prev
+
+
+def depth_gradient_enabled() -> bool:
+    return _DEPTH_GRADIENT
+
 # Per-device estimate of the instance count used to size the binning buffer BEFORE the count is known, so that
 # the forward never drains the GPU pipeline (include/splatraster.h: sr_forward).  Grows on demand.
 _CAPACITY = {}
@@ -74,7 +94,7 @@ class _ViewPack:
     """Keeps the contiguous camera tensors alive next to the C struct that points at them."""
 
     _cache: "dict" = {}
-    _CACHE_MAX = 1024
+    _CACHE_MAX = 256
 
     @classmethod
     def get(cls, rs: GaussianRasterizationSettings, device, sh_coeffs: int) -> "_ViewPack":
@@ -91,8 +111,10 @@ class _ViewPack:
         if hit is not None and hit[1] == versions and all(a is b for a, b in zip(hit[2], src)):
             return hit[0]
         pack = cls(rs, device, sh_coeffs)
-        if len(cls._cache) >= cls._CACHE_MAX:
-            cls._cache.clear()
+        while len(cls._cache) >= cls._CACHE_MAX:
+            # oldest entry first (dicts keep insertion order): callers that build a fresh `bg` per call -- the reference's mask
+            # pass does, gaussian_renderer/__init__.py:81 -- miss every time and would otherwise flush the training cameras
+            cls._cache.pop(next(iter(cls._cache)))
         cls._cache[key] = (pack, versions, src)
         return pack
 
@@ -239,7 +261,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = g(grad_color)
         if grad_color is None:
             grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
-        grad_depth, grad_alpha = g(grad_depth), g(grad_alpha)
+        grad_depth, grad_alpha = g(grad_depth if _DEPTH_GRADIENT else None), g(grad_alpha)
         view = ctx.view_pack  # camera tensors were made contiguous in forward
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         d_means3D, d_means2D, d_opac = new(n, 3), new(n, 3), new(n, 1)

@@ -31,6 +31,14 @@ def shard_views(views: Sequence, rank: int, world: int) -> list:
 # its transfer time; the SH gradient (192 MB) is reduced on its own, without a packing copy.
 PACK_BELOW_BYTES = 64 << 20
 
+# Tests only: issue the collectives even in a 1-rank group, so that a single MI355X exercises the RCCL calls
+# (ReduceOp.AVG, all_gather_into_tensor, device all_to_all_single) the multi-GPU steps rely on.
+FORCE_COLLECTIVES = False
+
+
+def _exchange(world: int) -> bool:
+    return world > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+
 
 def pack_gradients(grads: Sequence[torch.Tensor]):
     """One flat buffer holding ``grads`` back to back (one `cat` kernel) and, per tensor, a view of its segment."""
@@ -42,13 +50,29 @@ def pack_gradients(grads: Sequence[torch.Tensor]):
     return flat, views
 
 
-def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None) -> None:
+def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, *, sh_param: torch.Tensor = None,
+                        sh_active_coeffs: int = None) -> None:
     """Mean over ranks of every ``.grad``: large tensors are all-reduced in place (largest first, so its ring starts while
     the rest is queued), the small ones travel packed in one buffer and ``p.grad`` is re-pointed at its segment.
-    All collectives are issued asynchronously back to back and waited together."""
-    if world <= 1:
+    All collectives are issued asynchronously back to back and waited together.
+
+    Every rank must pass the same parameters: a parameter without a gradient on this rank (it rendered no view, or the
+    parameter did not reach its loss) takes part with zeros, so that all ranks issue the same collectives.
+
+    ``sh_param`` / ``sh_active_coeffs``: while ``active_sh_degree`` is below the stored degree (reference
+    scene/gaussian_model.py:118-120 raises it every 1000 iterations) the gradient of the inactive bands is exactly zero on
+    every rank; only the leading ``sh_active_coeffs`` coefficients of ``sh_param.grad`` [N, K, 3] are exchanged then."""
+    if not _exchange(world):
         return
-    params = [p for p in params if p.grad is not None]
+    params = list(params)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    sh_slice = None
+    if sh_param is not None and sh_active_coeffs is not None and sh_param.grad is not None and sh_param.grad.dim() == 3 \
+            and 0 < sh_active_coeffs < sh_param.grad.shape[1]:
+        params = [p for p in params if p is not sh_param]
+        sh_slice = sh_param.grad[:, :sh_active_coeffs].contiguous()
     big = sorted((p for p in params if p.grad.numel() * p.grad.element_size() >= PACK_BELOW_BYTES),
                  key=lambda p: -p.grad.numel())
     small = [p for p in params if p.grad.numel() * p.grad.element_size() < PACK_BELOW_BYTES]
@@ -56,6 +80,8 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None) 
     avg = dist.get_backend(group) == "nccl"
     op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
     works = [dist.all_reduce(p.grad, op=op, group=group, async_op=True) for p in big]
+    if sh_slice is not None:
+        works.append(dist.all_reduce(sh_slice, op=op, group=group, async_op=True))
     by_dtype = {}
     for p in small:
         by_dtype.setdefault(p.grad.dtype, []).append(p)
@@ -72,9 +98,13 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None) 
             p.grad.mul_(scale)
         for _, flat, _ in packed:
             flat.mul_(scale)
+        if sh_slice is not None:
+            sh_slice.mul_(scale)
     for ps, _, views in packed:
         for p, v in zip(ps, views):
             p.grad = v
+    if sh_slice is not None:
+        sh_param.grad[:, :sh_slice.shape[1]].copy_(sh_slice)
 
 
 def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
@@ -127,7 +157,7 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
             params[k].grad = torch.zeros_like(params[k])
     dcol_local = dcol_views[0][None] if len(dcol_views) == 1 else torch.stack(dcol_views)
     campos_all = _campos_of(cams, dev)
-    if world > 1:
+    if _exchange(world):
         gathered = torch.empty(world, len(mine), n, 3, dtype=torch.float32, device=dev)
         # the collectives run in issue order on RCCL's stream: the all-gather first (the SH rebuild needs it), then ONE
         # all-reduce of the four geometric gradients packed back to back (44 B/splat), which overlaps the SH rebuild
@@ -230,7 +260,7 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
     elif n_own > 0:      # short last shard: pad rows stay zero
         col_own, keep = shmod.sh_forward_views(m_own, sh_own, campos, sh_degree)     # [V, n_own, 3] each
         send.view(V, shard, 3)[:, :n_own].copy_(col_own)
-    if world > 1:
+    if _exchange(world):
         recv = torch.empty_like(send)
         _all_to_all(recv, send, group)
     else:
@@ -260,7 +290,7 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
             params[name].grad = torch.zeros_like(params[name])
 
     # 3. colour gradients back to the shard owners; SH gradient (and the view-direction term) of my shard from all views
-    if world > 1:
+    if _exchange(world):
         dcol_recv = torch.empty_like(dcol_send)
         _all_to_all(dcol_recv, dcol_send, group)
     else:
@@ -274,7 +304,7 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
         params["means3D"].grad[lo:hi] += d_means
 
     # 4. the geometric gradients of all views
-    if world > 1:
+    if _exchange(world):
         flat, views = pack_gradients([params[name].grad for name in names])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         for name, v_ in zip(names, views):
@@ -306,7 +336,7 @@ def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss:
         local = (total / n_views).detach()
     else:
         local = torch.zeros((), device=params[0].device, dtype=params[0].dtype)
-    if world > 1:
+    if _exchange(world):
         for p in params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

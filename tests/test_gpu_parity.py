@@ -209,6 +209,44 @@ def test_large_image_global_atomic_fallback(hip_device):
         assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
 
 
+def test_image_with_exactly_16384_tiles(hip_device):
+    """2048x2048 = 16384 tiles, the largest image on the count-matrix path: its per-workgroup LDS histogram is 64 KiB on top
+    of the kernels' static LDS, which needs the raised dynamic-LDS limit (k_count_tiles, k_emit)."""
+    sp, cam, st, grads = make_scene(30000, 2048, 2048, mean_scale=0.01, view=2)
+    assert (2048 // 16) * (2048 // 16) == 16384
+    out, g = run_hip(sp, st, grads, hip_device)
+    cout, cg, _ = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=8)
+    assert torch.equal(out["radii"], cout["radii"])
+    for k in ("color", "depth", "alpha"):
+        rel = (out[k].double() - cout[k].double()).abs() / cout[k].double().abs().clamp_min(1e-3)
+        assert (rel > 1e-4).float().mean().item() < 1e-4, k
+        assert (out[k].double() - cout[k].double()).abs().max().item() <= 2e-2 * max(1.0, cout[k].abs().max().item()), k
+    for k in cg:
+        assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
+
+
+def test_depth_gradient_switch(hip_device):
+    """SURVEY.md section 8f row 2: the depth image is differentiable by default (what reference train.py:217-229 needs);
+    set_depth_gradient(False) reproduces a rasterizer whose backward ignores dL/ddepth.  Both settings against the oracle's
+    autograd with and without the depth term."""
+    from splatfields_amd import rasterizer as rz
+    sp, cam, st, grads = make_scene(5000, 144, 112, view=3)
+    assert rz.depth_gradient_enabled()
+    _, g_on = run_hip(sp, st, grads, hip_device)
+    prev = rz.set_depth_gradient(False)
+    try:
+        _, g_off = run_hip(sp, st, grads, hip_device)
+    finally:
+        rz.set_depth_gradient(prev)
+    _, ref_on = O.fwd_bwd(sp, st, grads[0], grads[1], grads[2], use_sh=True, dtype=torch.float64)
+    _, ref_off = O.fwd_bwd(sp, st, grads[0], None, grads[2], use_sh=True, dtype=torch.float64)
+    for k in g_on:
+        assert grad_error(g_on[k], ref_on[k]) <= GRAD_TOL64, (k, "on")
+        assert grad_error(g_off[k], ref_off[k]) <= GRAD_TOL64, (k, "off")
+    # the two settings do differ (the depth term is not negligible in this scene)
+    assert grad_error(g_on["means3D"], ref_off["means3D"]) > 10 * GRAD_TOL64
+
+
 @pytest.mark.parametrize("with_depth,with_alpha", [(False, False), (True, False), (False, True)])
 def test_backward_variants_without_depth_or_alpha_gradients(hip_device, with_depth, with_alpha):
     """SplatFields' default losses use colour (+ alpha mask) only; the backward kernel has compiled-out variants."""

@@ -17,7 +17,7 @@ def backward_work(n, width, height, mean_scale=None, use_sh=True, view=1, device
     from splatfields_amd import _lib, rasterizer as rz
     from tests.helpers import make_scene, run_hip
     lib = _lib.load()
-    out8 = (C.c_ulonglong * 8)()
+    out8 = (C.c_ulonglong * 16)()
     sp, cam, st, grads = make_scene(n, width, height, mean_scale=mean_scale, view=view)
     lib.sr_debug_backward_stats(out8, 1)
     run_hip(sp, st, grads, torch.device(device), use_sh=use_sh)
@@ -26,7 +26,11 @@ def backward_work(n, width, height, mean_scale=None, use_sh=True, view=1, device
     return {"splats": n, "width": width, "height": height, "mean_scale": mean_scale, "tile_instances": int(rz.LAST_INSTANCES),
             "list_entries_replayed": e, "quad_entry_pairs": qe, "buckets": bk, "pairs_evaluated": pe, "pairs_blended": pb,
             "chunks": ch, "lane_efficiency": (pb / pe) if pe else None,
-            "bucket_fill": (qe / (16.0 * bk)) if bk else None}
+            "bucket_fill": (qe / (16.0 * bk)) if bk else None,
+            "phase_cycles_share": (lambda ph: {k: round(x / max(sum(ph), 1), 4) for k, x in zip(
+                ["preamble", "test", "barrier1", "assign+scatter", "barrier2", "replay", "barrier3", "combine"], ph)})(
+                [int(out8[8 + i]) for i in range(8)]),
+            "wave_cycles_total": sum(int(out8[8 + i]) for i in range(8))}
 
 
 if __name__ == "__main__":
