@@ -39,12 +39,19 @@ def parse():
     p.add_argument("--sh-degree", type=int, default=3)
     p.add_argument("--cpu-baseline", choices=["auto", "none"], default="auto")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded baseline sample")
-    p.add_argument("--dp-mode", choices=["shard", "gather", "allreduce"], default="shard",
-                   help="N>1, SH path: 'shard' = SH coefficients sharded by splat range, colours and colour gradients travel by "
-                        "all-to-all (view_parallel.sh_sharded_step, ~98 B/splat on the wire); 'gather' = all-gather of 12 B/splat "
-                        "colour gradients, SH gradient rebuilt on every rank (sh_gather_step, ~161 B/splat); 'allreduce' = "
-                        "sum-all-reduce of all five gradient tensors (~413 B/splat).  A mode that fails on any rank falls back "
-                        "to the next one on all ranks.")
+    p.add_argument("--dp-mode", choices=["shard", "gather", "allreduce"], default="gather",
+                   help="N>1, SH path.  'gather' (default) = all-gather of 12 B/splat colour gradients, the SH gradient is rebuilt "
+                        "on every rank (sh_gather_step, ~161 B/splat on the wire): afterwards EVERY rank holds the full gradient "
+                        "of all five tensors -- what the reference's replicated Adam consumes; 'allreduce' = the same result by "
+                        "sum-all-reduce of all five gradient tensors (~413 B/splat); 'shard' = SH coefficients sharded by splat "
+                        "range, colours and colour gradients travel by all-to-all (sh_sharded_step, ~98 B/splat): the SH gradient "
+                        "then exists only on its owner (a sharded optimizer), so it is a different deliverable and never the "
+                        "default.  A mode that fails on any rank falls back to the next one on all ranks.")
+    p.add_argument("--mean-scale", type=float, default=None, help="mean splat scale in world units (default: SURVEY.md 8d rule, "
+                                                                   "0.35 N^(-1/3)); larger = denser tile lists")
+    p.add_argument("--extra-workloads", choices=["auto", "none"], default="auto",
+                   help="rank 0, 1 GPU: also time the precomputed-colour headline and two dense regimes (a few steps each) and "
+                        "report them under other_workloads")
     p.add_argument("--inputs", choices=["boundary", "raw-split"], default="boundary",
                    help="'boundary' (default, the reference's call): activated tensors and the concatenated SH tensor; 'raw-split': "
                         "the optimiser's raw parameters (logits, log-scales, unnormalised quaternions) and the two SH tensors "
@@ -81,6 +88,123 @@ def pipeline_bytes(n: int, vis: float, R: float, hw: int, c_in: int) -> float:
     return n * (3 * (44 + c_in) + 16) + vis * 160 + R * 164 + hw * 48
 
 
+
+def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, warmup, dev):
+    """ms per fwd+bwd step and per-stage HIP-event times of one more single-GPU workload (same step as the headline)."""
+    import math
+    from splatfields_amd import _lib, rasterizer as rz
+    from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    lib = _lib.load()
+    sp = make_splats(n, seed=1234, device=dev, mean_scale=mean_scale)
+    names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
+    params = {k: sp[k].clone().requires_grad_(True) for k in names}
+    gi, gd, ga = make_upstream_grads(height, width, device=dev)
+    bg = torch.ones(3, device=dev)
+    cams = [make_camera(k, width, height, device=dev) for k in range(8)]
+    vis = [0.0]
+
+    def step(i, record=False):
+        cam = cams[i % len(cams)]
+        rs = GaussianRasterizationSettings(
+            image_height=height, image_width=width, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
+            scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=sh_degree,
+            campos=cam.camera_center, prefiltered=False, debug=False)
+        for p in params.values():
+            p.grad = None
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"], requires_grad=True),
+            opacities=params["opacities"], shs=params["shs"] if use_sh else None,
+            colors_precomp=None if use_sh else params["colors_precomp"], scales=params["scales"], rotations=params["rotations"])
+        torch.autograd.backward((color, depth, alpha), (gi, gd, ga))
+        if record:
+            vis[0] = float((radii > 0).sum().item())
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    ms_per_step = (time.perf_counter() - t0) / steps * 1e3
+    lib.sr_profile_enable(1)
+    for i in range(steps):
+        step(warmup + i, record=(i == steps - 1))
+    torch.cuda.synchronize()
+    ms = (C.c_double * _lib.PROFILE_STAGES)()
+    cnt = (C.c_longlong * _lib.PROFILE_STAGES)()
+    lib.sr_profile_collect(ms, cnt)
+    lib.sr_profile_enable(0)
+    stage_ms = {lib.sr_profile_stage_name(i).decode(): (ms[i] / max(cnt[i], 1)) for i in range(_lib.PROFILE_STAGES)}
+    R = float(rz.LAST_INSTANCES)
+    c_in = 12 * 16 if use_sh else 12
+    b_alg = pipeline_bytes(n, vis[0], R, height * width, c_in)
+    binning = stage_ms["scan"] + stage_ms["emit"] + stage_ms["sort_tiles"]
+    blend = stage_ms["render_forward"] + stage_ms["render_backward"]
+    return {"splats": n, "width": width, "height": height, "mean_scale": mean_scale,
+            "color": "sh%d" % sh_degree if use_sh else "precomp", "steps": steps, "ms_per_step": ms_per_step,
+            "value": n * height * width / (ms_per_step * 1e-3), "tile_instances": R, "instances_per_splat": R / n,
+            "visible_splats": vis[0], "stage_ms": stage_ms, "binning_over_blend": binning / blend if blend > 0 else None,
+            "sort_keys_per_s": R / (stage_ms["sort_tiles"] * 1e-3) if stage_ms["sort_tiles"] > 0 else None,
+            "roofline_pipeline_frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK}
+
+
+def blend_work_counters(n, width, height, mean_scale):
+    """pairs_evaluated / pairs_blended of the backward blend, counted by the SR_BWD_STATS build of the
+    same sources on ONE fwd+bwd of view 1, in its own process (tools/bwd_stats.py with SPLATRASTER_LIB pointing at the
+    counting build): a separate library, never the timed path."""
+    import subprocess
+    from splatfields_amd import build as b
+    if not b.STATS_LIB_PATH.exists():
+        return None
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bwd_stats.py"), "--splats", str(n), "--width", str(width), "--height", str(height)]
+    if mean_scale is not None:
+        cmd += ["--mean-scale", str(mean_scale)]
+    env = dict(os.environ, SPLATRASTER_LIB=str(b.STATS_LIB_PATH))
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    ph = d.pop("phase_cycles_share", {})
+    share = {}
+    for k, x in ph.items():
+        k = "barrier" if k.startswith("barrier") else k
+        share[k] = round(share.get(k, 0.0) + x, 4)
+    return {"kernel": "render_backward", "list_entries_replayed": d["list_entries_replayed"], "quad_entry_pairs": d["quad_entry_pairs"],
+            "buckets_of_16": d["buckets"], "pairs_evaluated": d["pairs_evaluated"], "pairs_blended": d["pairs_blended"],
+            "lane_efficiency": d["lane_efficiency"], "bucket_fill": d["bucket_fill"], "list_chunks": d["chunks"],
+            "wave_cycle_share_by_phase": share,
+            "note": "pair = (pixel, list entry) on which alpha is evaluated; blended = alpha >= 1/255 and not behind the pixel's "
+                    "last contributor; counted on one fwd+bwd of view 1 by the -DSR_BWD_STATS build (tools/bwd_stats.py)"}
+
+
+def valu_roofline(workload: dict, stage_ms: dict):
+    """Issue-side roofline of the two blend kernels from the committed SQ counter passes (profiles/pmc_sq.json, rocprofv3
+    --pmc, per-launch averages): wave-level VALU / SALU instruction counts and the share of the launch during which the
+    SIMDs' VALU was busy (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles).  The counters are a recorded
+    measurement of this workload; the launch duration next to them is the live one."""
+    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        pj = json.load(open(path))
+    except Exception:
+        return None
+    if pj.get("_workload") != workload:
+        return None
+    out = {"source": pj.get("_source"), "simds": 1024}
+    for stage in ("render_forward", "render_backward"):
+        c = pj.get(stage)
+        if not c:
+            continue
+        cycles = c["SQ_BUSY_CYCLES"] / 32.0            # summed over the 32 shader engines
+        out[stage] = {"wave_valu_insts_per_launch": c["SQ_INSTS_VALU"], "wave_salu_insts_per_launch": c["SQ_INSTS_SALU"],
+                      "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "mfma_insts_per_launch": c.get("SQ_INSTS_MFMA"),
+                      "kernel_cycles": cycles, "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles,
+                      "cycles_per_valu_inst_per_simd": cycles * 1024.0 / c["SQ_INSTS_VALU"],
+                      "live_avg_launch_ms": stage_ms.get(stage)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +233,7 @@ def main():
     N, H, W = args.splats, args.height, args.width
     use_sh = args.color == "sh"
     c_in = 12 * 16 if use_sh else 12
-    sp = make_splats(N, seed=1234, device=dev)
+    sp = make_splats(N, seed=1234, device=dev, mean_scale=args.mean_scale)
     names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
     params = {k: sp[k].clone().requires_grad_(True) for k in names}
     raw_split = args.inputs == "raw-split" and use_sh
@@ -120,7 +244,7 @@ def main():
     gi, gd, ga = make_upstream_grads(H, W, device=dev)
     bg = torch.ones(3, device=dev)
     cams = [make_camera(k, W, H, device=dev) for k in range(8)]
-    stats = {"R": 0.0, "vis": 0.0, "n": 0}
+    stats = {"R": 0.0, "vis": 0.0, "n": 0, "vis_probe": float(N)}
 
     dp_active = (world > 1 or args.force_dp_path) and use_sh
     modes = {"shard": ["shard", "gather", "allreduce"], "gather": ["gather", "allreduce"], "allreduce": ["allreduce"]}[args.dp_mode]
@@ -140,7 +264,7 @@ def main():
             sh_gather_step(params, step_cams, bg, args.sh_degree, bwd, rank=rank, world=world)
         if record:
             stats["R"] += rz.LAST_INSTANCES
-            stats["vis"] += float(N)
+            stats["vis"] += stats["vis_probe"]
             stats["n"] += 1
 
     def one_step(step_idx: int, record: bool = False):
@@ -180,6 +304,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if dp_active:   # visible splats of one view, for the byte model (the exchange steps do not hand the radii out)
+        cam0 = cams[0]
+        rs0 = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam0.FoVx * 0.5), tanfovy=math.tan(cam0.FoVy * 0.5), bg=bg,
+            scale_modifier=1.0, viewmatrix=cam0.world_view_transform, projmatrix=cam0.full_proj_transform,
+            sh_degree=args.sh_degree, campos=cam0.camera_center, prefiltered=False, debug=False)
+        with torch.no_grad():
+            _, radii0, _ = GaussianRasterizer(rs0)(means3D=sp["means3D"], means2D=torch.zeros_like(sp["means3D"]),
+                                                   opacities=sp["opacities"], shs=sp["shs"], scales=sp["scales"],
+                                                   rotations=sp["rotations"])
+        stats["vis_probe"] = float((radii0 > 0).sum().item())
     while dp_active and state["mode"] != "allreduce":
         # make sure every rank can run this exchange; otherwise all ranks fall back to the next mode together
         ok = torch.ones(1, device=dev)
@@ -194,6 +329,7 @@ def main():
         if ok.item() != 0:
             break
         state["mode"] = modes[modes.index(state["mode"]) + 1]
+    t_start = time.perf_counter()
     for i in range(args.warmup):
         one_step(i)
     fence()
@@ -208,6 +344,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * N * H * W * args.steps / elapsed
 
+    def progress(msg):
+        if rank == 0:
+            print(f"[bench] {msg} (+{time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
+
+    progress(f"timed {args.steps} steps: {ms_per_step:.4f} ms/step")
     # ---- per-stage durations with HIP events on the launch stream (same steps, same inputs) ----
     lib.sr_profile_enable(1)
     for i in range(args.steps):
@@ -260,8 +401,33 @@ def main():
         # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
         "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }
+    progress("stage pass done")
+    wl = {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree, "mean_scale": args.mean_scale}
+    out["roofline_valu"] = valu_roofline(wl, stage_ms)
+    out["roofline"]["note"] = ("the blend kernels are VALU-issue-bound, not HBM-bound: see roofline_valu (SQ counters) and blend_work "
+                               "(pairs evaluated / blended); `traffic` is L2<->fabric bytes incl. requests served by the 256 MB "
+                               "infinity cache; the HBM-bound stages are preprocess / preprocess_backward (DESIGN.md section 5)")
+    if rank == 0 and world == 1 and args.extra_workloads != "none":
+        try:
+            out["blend_work"] = blend_work_counters(N, W, H, args.mean_scale)
+        except Exception as e:  # noqa: BLE001 -- a missing counting build must not cost the headline line
+            out["blend_work"] = {"error": repr(e)}
+        progress("blend_work done")
+    if rank == 0 and world == 1 and args.extra_workloads != "none":
+        # SURVEY.md 8d "both colour paths" + denser tile lists (trained scenes sit at 5-15 instances per splat)
+        extra = [("headline, precomputed colours", N, W, H, False, args.mean_scale),
+                 ("dense: 300 k splats, mean scale 0.02", 300_000, 800, 800, True, 0.02),
+                 ("dense: 100 k splats, mean scale 0.05", 100_000, 800, 800, True, 0.05)]
+        out["other_workloads"] = []
+        for name, n_, w_, h_, sh_, ms_ in extra:
+            r = time_plain_workload(n_, w_, h_, sh_, ms_, args.sh_degree, 20, 8, dev)
+            r["name"] = name
+            out["other_workloads"].append(r)
+            progress(f"workload '{name}' done")
     if rank == 0 and world == 1 and args.cpu_baseline != "none":
-        from oracle.cpu_baseline import run_cpu_baseline  # the oracle is used here only as the timed CPU baseline
+        from oracle.cpu_baseline import run_cpu_baseline, run_torch_oracle_config0  # the oracle: only the timed CPU baseline
+        out["cpu_baseline_torch_config0"] = run_torch_oracle_config0()
+        progress("torch oracle config 0 done")
         out["cpu_baseline"] = run_cpu_baseline(N, H, W, use_sh, args.sh_degree, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))

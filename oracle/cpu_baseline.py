@@ -44,3 +44,27 @@ def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_de
             "sample": f"C oracle (oracle/raster_ref.c, OpenMP {cores} threads), fwd+bwd of view 0 of the same workload: "
                       f"all {n_splats} splats preprocessed and binned, tile rows {y0}..{y0 + rows_full} of {gy} "
                       f"({frac:.0%} of the image, {px}x{width} px) blended and back-propagated"}
+
+
+def run_torch_oracle_config0():
+    """the PyTorch-CPU render path (the differentiable torch oracle in fp32 -- the stand-in for "the
+    reference's PyTorch-CPU render path", which the reference does not have) at BASELINE.json configs[0]: 10 k splats, one
+    256x256 camera, forward + autograd backward.  PyTorch's CPU kernels are run on at most 16 threads: the oracle issues
+    ~10^5 small tensor ops, and a fork-join over 256 host threads per op takes minutes where 16 threads take seconds
+    (`cores` reports the threads actually used)."""
+    from oracle import torch_oracle as O
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    cores = min(16, os.cpu_count() or 1)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    n, w, h = 10_000, 256, 256
+    sp = make_splats(n, seed=1234)
+    st = O.settings_from_camera(make_camera(1, w, h), torch.ones(3), 3)
+    gi, gd, ga = make_upstream_grads(h, w)
+    t0 = time.perf_counter()
+    O.fwd_bwd(sp, st, gi, gd, ga, use_sh=True, dtype=torch.float32)
+    t = time.perf_counter() - t0
+    torch.set_num_threads(prev)
+    return {"value": n * w * h / t, "unit": "splat*px/s", "cores": cores, "kind": "port", "seconds": t,
+            "sample": f"oracle/torch_oracle.py (PyTorch CPU, fp32, autograd backward), {n} splats, {w}x{h}, one fwd+bwd, "
+                      f"torch threads = {cores}"}

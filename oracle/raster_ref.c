@@ -155,6 +155,9 @@ int ref_rasterize(const RefView* v, int N, const float* means3D, const float* op
     const float* vm = v->viewmatrix; const float* pm = v->projmatrix;
     if (tile_x1 <= tile_x0 || tile_y1 <= tile_y0) { tile_x0 = 0; tile_y0 = 0; tile_x1 = gx; tile_y1 = gy; }
 #ifdef _OPENMP
+    /* the caller's process shares this OpenMP runtime (PyTorch's CPU kernels): the team size is restored on the way out,
+     * otherwise every later small tensor op runs on `threads` threads */
+    const int omp_prev_threads = omp_get_max_threads();
     if (threads > 0) omp_set_num_threads(threads);
 #endif
     float* xy = (float*)malloc(sizeof(float) * 2 * (size_t)(N + 1));
@@ -437,5 +440,8 @@ int ref_rasterize(const RefView* v, int N, const float* means3D, const float* op
     }
     free(xy); free(con_o); free(rgb); free(depth); free(rect); free(clamped); free(tile_cnt); free(tile_start); free(list);
     free(final_T); free(n_contrib);
+#ifdef _OPENMP
+    omp_set_num_threads(omp_prev_threads);
+#endif
     return 0;
 }

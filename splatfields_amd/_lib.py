@@ -71,6 +71,16 @@ SR_RAW_SCALES, SR_RAW_OPACITY, SR_RAW_ROTATIONS, SR_FORWARD_ONLY = 1, 2, 4, 8
 _lib = None
 
 
+def bind(path) -> C.CDLL:
+    """dlopen a build of the library and attach the prototypes of every declared symbol."""
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load() -> C.CDLL:
     """Loads libsplatraster.so once; fails loudly when it has not been built."""
     global _lib
@@ -79,13 +89,25 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m splatfields_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        lib = C.CDLL(str(LIB_PATH))
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = bind(LIB_PATH)
     return _lib
+
+
+class use_library:
+    """Context manager: route the facade through another build of the same ABI (bench.py's counting build)."""
+
+    def __init__(self, path):
+        self.handle = bind(path)
+
+    def __enter__(self):
+        global _lib
+        self.prev, _lib = _lib, self.handle
+        return self.handle
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(status: int) -> None:

@@ -9,6 +9,9 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libsplatraster.so"
+# same ABI with the work counters of the backward blend compiled in (-DSR_BWD_STATS): measurement aid of bench.py
+# (pairs_evaluated / pairs_blended), never the timed path
+STATS_LIB_PATH = PKG_DIR / "libsplatraster_stats.so"
 SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "blend_bwd.hip", "knn.hip", "sh.hip"]
 HEADERS = ["common.h", "kernels.h", "expand.h", "sh_stage.h", "quadmask.h", "../../include/splatraster.h"]
 
@@ -43,6 +46,13 @@ def build_library(force: bool = False, verbose: bool = False, out: Path = None, 
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=str(CSRC))
     return target
+
+
+def build_stats_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and STATS_LIB_PATH.exists() and not any(
+            (CSRC / f).stat().st_mtime > STATS_LIB_PATH.stat().st_mtime for f in SOURCES + HEADERS):
+        return STATS_LIB_PATH
+    return build_library(force=True, verbose=verbose, out=STATS_LIB_PATH, defines=["SR_BWD_STATS"])
 
 
 if __name__ == "__main__":

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# OpenMP workers of the C oracle (libgomp) and of PyTorch's CPU kernels must not busy-wait between parallel regions: two
+# runtimes spinning on every host core starve each other (observed on the 256-thread GPU box)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -81,3 +81,16 @@ def radii_mismatch(hip_radii, pre, tol=2e-3):
     near_cull = (pre.depth.to(torch.float64) - 0.2).abs() < 1e-5
     # marginal tile-rect emptiness: bounding square touches the tile grid edge within tol
     return int((diff & ~near_int & ~near_cull).sum())
+
+
+def assert_grads_flip_aware(hip: dict, ref: dict, tag="", *, bulk_tol=1e-3, max_tol=5e-3, outliers=1e-5):
+    """fp32 kernels vs the fp32 C oracle on LARGE scenes: among millions of gradient elements a handful sit on pixel-splat
+    pairs whose threshold decision (alpha >= 1/255, T >= 1e-4) flips between the two fp32 evaluations, which moves them by a
+    discrete amount.  Every element within `max_tol` of the tensor's maximum (the flip-aware bound of the fp64 comparisons),
+    all but a fraction `outliers` within `bulk_tol` (the bound of the small-scene fp32 comparisons), median <= 1e-6."""
+    for k in ref:
+        b = ref[k].double()
+        err = (hip[k].double() - b).abs() / b.abs().max().clamp_min(1e-30)
+        assert err.max().item() <= max_tol, (tag, k, err.max().item())
+        assert (err > bulk_tol).float().mean().item() <= outliers, (tag, k, (err > bulk_tol).float().mean().item())
+        assert err.median().item() <= 1e-6, (tag, k)

@@ -4,7 +4,7 @@ invariance, and a 6 M-splat run."""
 import pytest
 import torch
 
-from tests.helpers import make_scene, run_hip
+from tests.helpers import assert_grads_flip_aware, make_scene, run_hip
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,7 @@ def test_window_against_c_oracle(hip_device, scene):
 
 def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, scene):
     """BASELINE.json's metric configuration (1 M splats, 800x800, SH degree 3): the WHOLE image and ALL six gradient
-    tensors against the fp32 C oracle (OpenMP over the host cores: ~2 s on the GPU box), with the criteria of the
+    tensors against the fp32 C oracle (OpenMP, up to 64 threads: a few seconds on the GPU box), with the criteria of the
     small-scene parity tests: images <= 1e-4 relative on the robust pixels (a pixel whose threshold decision flips between
     two fp32 evaluations may differ by one blended pair: <= 2e-2); gradients: among the 3-48 million elements of a tensor a
     handful sit on pixel-splat pairs whose threshold decision flips between the two fp32 evaluations, which moves them by a
@@ -75,8 +75,11 @@ def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, s
     from oracle import c_oracle
     sp, cam, st, grads = scene
     out, g = run_hip(sp, st, grads, hip_device)
+    # a moderate OpenMP team (the oracle restores the process-wide team size afterwards; PyTorch's CPU kernels share the
+    # runtime)
+    threads = min(64, os.cpu_count() or 8)
     ref, rg, num_rendered = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2],
-                                               threads=os.cpu_count() or 8)
+                                               threads=threads)
     assert torch.equal(out["radii"], ref["radii"])
     for k in ("color", "depth", "alpha"):
         a, b = out[k].double(), ref[k].double()
@@ -84,22 +87,13 @@ def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, s
         assert rel.median().item() < 1e-5, k
         assert (rel > 1e-4).float().mean().item() < 5e-3, k   # both sides fp32: a few pixels flip a threshold decision
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
-    def check_grads(hip, ref_g, tag):
-        for k in ref_g:
-            b = ref_g[k].double()
-            err = (hip[k].double() - b).abs() / b.abs().max().clamp_min(1e-30)
-            assert err.max().item() <= 5e-3, (tag, k, err.max().item())
-            assert (err > 1e-3).float().mean().item() <= 1e-5, (tag, k, (err > 1e-3).float().mean().item())
-            assert err.median().item() <= 1e-6, (tag, k)
-
-    check_grads(g, rg, "sh")
+    assert_grads_flip_aware(g, rg, "sh")
     # the same for the precomputed-colour path of the headline ("both colour paths")
     out2, g2 = run_hip(sp, st, grads, hip_device, use_sh=False)
-    ref2, rg2, _ = c_oracle.rasterize(sp, st, use_sh=False, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2],
-                                      threads=os.cpu_count() or 8)
+    ref2, rg2, _ = c_oracle.rasterize(sp, st, use_sh=False, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=threads)
     rel = (out2["color"].double() - ref2["color"].double()).abs() / ref2["color"].double().abs().clamp_min(1e-3)
     assert rel.median().item() < 1e-5 and (rel > 1e-4).float().mean().item() < 5e-3
-    check_grads(g2, rg2, "precomputed colours")
+    assert_grads_flip_aware(g2, rg2, "precomputed colours")
 
 
 def test_six_million_splats_chunked_count_matrix(hip_device):

@@ -16,7 +16,7 @@ import torch
 from oracle import c_oracle
 from oracle import torch_oracle as O
 from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-from tests.helpers import grad_error, image_errors, make_scene, radii_mismatch, run_hip
+from tests.helpers import assert_grads_flip_aware, grad_error, image_errors, make_scene, radii_mismatch, run_hip
 from tests.test_oracle_cross import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -221,8 +221,7 @@ def test_image_with_exactly_16384_tiles(hip_device):
         rel = (out[k].double() - cout[k].double()).abs() / cout[k].double().abs().clamp_min(1e-3)
         assert (rel > 1e-4).float().mean().item() < 1e-4, k
         assert (out[k].double() - cout[k].double()).abs().max().item() <= 2e-2 * max(1.0, cout[k].abs().max().item()), k
-    for k in cg:
-        assert grad_error(g[k], cg[k]) <= GRAD_TOL32, k
+    assert_grads_flip_aware(g, cg, "2048x2048", outliers=1e-4)   # 30 k splats: 1e-4 of the elements = a handful
 
 
 def test_depth_gradient_switch(hip_device):

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("src")
     ap.add_argument("prefix")
     ap.add_argument("--traffic")
+    ap.add_argument("--sq", help="write the per-launch SQ counters of the two blend kernels (bench.py's roofline_valu) here")
     a = ap.parse_args()
 
     shutil.copy(os.path.join(a.src, "bench.json"), a.prefix + "_bench.json")
@@ -61,7 +62,10 @@ def main():
 
     out = defaultdict(dict)
     launches = {}
-    for sub, unit in (("pmc_fetch", "_KB_per_launch"), ("pmc_write", "_KB_per_launch"), ("pmc_sq", "_per_launch")):
+    for sub, unit in (("pmc_fetch", "_KB_per_launch"), ("pmc_write", "_KB_per_launch"), ("pmc_sq", "_per_launch"),
+                      ("pmc_sq2", "_per_launch")):
+        if not os.path.exists(os.path.join(a.src, sub, "r_counter_collection.csv")):
+            continue
         vals, n = per_launch(os.path.join(a.src, sub, "r_counter_collection.csv"))
         for k, cs in vals.items():
             for c, v in cs.items():
@@ -72,6 +76,18 @@ def main():
         if "FETCH_SIZE_KB_per_launch" in d and "WRITE_SIZE_KB_per_launch" in d:
             d["hbm_bytes_per_launch_corrected"] = (2 * d["FETCH_SIZE_KB_per_launch"] + d["WRITE_SIZE_KB_per_launch"]) * 1024
     json.dump(out, open(a.prefix + "_pmc.json", "w"), indent=1, sort_keys=True)
+
+    if a.sq:
+        bench = json.load(open(os.path.join(a.src, "bench.json")))
+        cfg = bench["config"]
+        sq = {"_workload": {"splats": cfg["splats"], "width": cfg["width"], "height": cfg["height"], "color": "sh", "sh_degree": 3,
+                            "mean_scale": None},
+              "_source": "%s_pmc.json (rocprofv3 --pmc SQ_* passes of tools/profile.sh, means per launch)" % a.prefix}
+        for k, d in out.items():
+            for prefix, s in (("sr::k_render_forward", "render_forward"), ("sr::k_render_backward", "render_backward")):
+                if k.startswith(prefix):
+                    sq[s] = {c[:-len("_per_launch")]: v for c, v in d.items() if c.startswith("SQ_")}
+        json.dump(sq, open(a.sq, "w"), indent=1, sort_keys=True)
 
     if a.traffic:
         bench = json.load(open(os.path.join(a.src, "bench.json")))
