@@ -187,6 +187,29 @@ int sr_sh_backward(int n_splats, int sh_coeffs, int sh_degree, int n_views, cons
 size_t sr_knn_workspace_bytes(int n_points);
 int sr_knn3_mean_dist2(int n_points, const float* points, float* mean_dist2, void* workspace, void* hip_stream);
 
+/* Densification / pruning of the splat set on the device: reference scene/gaussian_model.py:411-425 (`densify_and_prune`) with
+ * :394-409 (`densify_and_clone`), :355-380 (`densify_and_split`, N = 2), :306-353 (`densification_postfix`) and :272-304
+ * (`prune_points`), planned together.  Inputs are the optimiser's RAW parameters (log-scales [N,1|3], opacity logits [N]) and
+ * the densification statistics (`xyz_gradient_accum` [N], `denom` [N], `max_radii2D` [N] or NULL = not tested).
+ *
+ * sr_densify_plan writes dest [4][N] (int32): the row, in the final tensors, of splat i itself (k = 0), of its clone (k = 1)
+ * and of its two split children (k = 2, 3), or -1 -- in the order the reference's cat / mask sequence produces:
+ * [surviving originals][clones][first children][second children] -- and returns counts5 = rows of each kind + their sum.
+ * It synchronises the stream once (the caller needs the new size to allocate).  `workspace`: sr_densify_workspace_bytes(N).
+ *
+ * sr_densify_gather builds one final tensor from one source tensor of [N, row_floats]:
+ *   mode 0  every surviving row is a copy (features, opacity, rotation);
+ *   mode 1  Adam moment: the splat's own row is copied, new rows are zero (cat_tensors_to_optimizer);
+ *   mode 2  positions [N,3]: children = xyz + build_rotation(rotation) (unit_normal * exp(log_scale)), unit_normals [2][N][3];
+ *   mode 3  log-scales: children = log(exp(log_scale) / (0.8 * 2)). */
+size_t sr_densify_workspace_bytes(int n_splats);
+int sr_densify_plan(int n_splats, const float* log_scales, int scale_cols, const float* opacity_logits, const float* grad_accum,
+                    const float* denom, const float* max_radii2D, float grad_threshold, float min_opacity, float extent,
+                    float percent_dense, float max_screen_size, void* workspace, int* dest, long long* counts5, void* hip_stream);
+int sr_densify_gather(int n_splats, int row_floats, const float* src, float* dst, const int* dest, int mode,
+                      const float* log_scales, int scale_cols, const float* rotations, const float* unit_normals,
+                      void* hip_stream);
+
 /* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
  * (`instances` = the capacity the binning buffer was carved for):
  *   out[0]  geom:    tile_start  uint32[tiles + 1]   first list entry of every 16x16 tile (row-major tiles)

@@ -56,6 +56,11 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sr_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "sr_knn3_mean_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_densify_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "sr_densify_plan": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
+    "sr_densify_gather": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "sr_debug_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_size_t)]),
     "sr_debug_backward_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sr_profile_enable": (C.c_int, [C.c_int]),

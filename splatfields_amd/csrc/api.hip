@@ -307,6 +307,40 @@ int sr_knn3_mean_dist2(int n, const float* points, float* mean_dist2, void* work
     return check_hip(hipGetLastError(), "knn3");
 }
 
+size_t sr_densify_workspace_bytes(int n) { return sr::densify_workspace_bytes(n); }
+
+int sr_densify_plan(int n, const float* log_scales, int scale_cols, const float* opacity_logits, const float* grad_accum,
+                    const float* denom, const float* max_radii2D, float grad_threshold, float min_opacity, float extent,
+                    float percent_dense, float max_screen_size, void* workspace, int* dest, long long* counts5, void* hip_stream) {
+    if (n < 0 || (scale_cols != 1 && scale_cols != 3)) return fail("bad arguments to sr_densify_plan");
+    if (!counts5) return fail("null counts in sr_densify_plan");
+    for (int k = 0; k < 5; ++k) counts5[k] = 0;
+    if (n == 0) return 0;
+    if (!log_scales || !opacity_logits || !grad_accum || !denom || !workspace || !dest) return fail("null pointer in sr_densify_plan");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::DensifyArgs a{grad_threshold, min_opacity, extent, percent_dense, max_screen_size};
+    uint32_t* totals = nullptr;
+    sr::launch_densify_plan(n, log_scales, scale_cols, opacity_logits, grad_accum, denom, max_radii2D, a, workspace, dest, &totals, st);
+    SR_TRY(check_hip(hipGetLastError(), "densify_plan"));
+    uint32_t host[5];
+    SR_TRY(check_hip(hipMemcpyAsync(host, totals, sizeof(host), hipMemcpyDeviceToHost, st), "read densify counts"));
+    SR_TRY(check_hip(hipStreamSynchronize(st), "sync after densify_plan"));
+    for (int k = 0; k < 5; ++k) counts5[k] = (long long)host[k];
+    return 0;
+}
+
+int sr_densify_gather(int n, int row_floats, const float* src, float* dst, const int* dest, int mode, const float* log_scales,
+                      int scale_cols, const float* rotations, const float* unit_normals, void* hip_stream) {
+    if (n < 0 || row_floats <= 0 || mode < 0 || mode > 3) return fail("bad arguments to sr_densify_gather");
+    if (n == 0) return 0;
+    if (!src || !dst || !dest) return fail("null pointer in sr_densify_gather");
+    if (mode == 2 && (row_floats != 3 || !log_scales || !rotations || !unit_normals || (scale_cols != 1 && scale_cols != 3)))
+        return fail("sr_densify_gather mode 2 (positions) needs [N,3] rows, log-scales, rotations and unit normals");
+    sr::launch_densify_gather(n, row_floats, src, dst, dest, mode, log_scales, scale_cols, rotations, unit_normals,
+                              static_cast<hipStream_t>(hip_stream));
+    return check_hip(hipGetLastError(), "densify_gather");
+}
+
 int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {
     if (!out4 || n < 0 || h <= 0 || w <= 0 || instances < 0) return fail("bad arguments to sr_debug_layout");
     sr::Geom g; sr::Binning b;

@@ -44,6 +44,15 @@ void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b
 
 int backward_stats(unsigned long long* out8, int reset);
 
+// densify.hip
+struct DensifyArgs { float grad_threshold, min_opacity, extent, percent_dense, max_screen_size; };
+size_t densify_workspace_bytes(int n);
+void launch_densify_plan(int n, const float* log_scales, int scale_cols, const float* opacity_logit, const float* grad_accum,
+                         const float* denom, const float* max_radii2D, const DensifyArgs& a, void* workspace, int32_t* dest,
+                         uint32_t** totals_out, hipStream_t st);
+void launch_densify_gather(int n, int row, const float* src, float* dst, const int32_t* dest, int mode, const float* log_scales,
+                           int scale_cols, const float* rotations, const float* unit, hipStream_t st);
+
 // knn.hip
 size_t knn_workspace_bytes(int n);
 void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream_t st);
