@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SR_VERSION 1
+#define SR_VERSION 2
 #define SR_TILE 16 /* binning tile edge in pixels (upstream BLOCK_X = BLOCK_Y) */
 
 typedef struct SrView {
@@ -143,11 +143,16 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
                long long* instances_out, void* hip_stream);
 
 /* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero).  `instances` is the capacity the binning
- * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes. */
+ * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes.
+ * `instances_rendered`: the instance count the forward reported for these buffers (*instances_out), or -1 if the caller did
+ * not keep it.  It only selects between the two backward blend kernels, which produce the same gradient slots: small
+ * footprints (fewer than SR_BWD_WAVE_KERNEL_ABOVE instances per splat) replay on the entry-per-lane MFMA kernel
+ * (blend_bwd.hip), large footprints on the pixel-per-lane kernel (render.hip); unknown = the former. */
+#define SR_BWD_WAVE_KERNEL_ABOVE 6
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
-                long long instances, const void* image, const int* radii, const float* dL_dcolor,
-                const float* dL_ddepth, const float* dL_dalpha, void* scratch, const SrGrads* grads,
-                void* hip_stream);
+                long long instances, long long instances_rendered, const void* image, const int* radii,
+                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                const SrGrads* grads, void* hip_stream);
 
 /* present[i] = 1 iff splat i passes the near-plane test (view z > 0.2). */
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,

@@ -216,9 +216,9 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
 }
 
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
-                long long instances, const void* image, const int* radii, const float* dL_dcolor,
-                const float* dL_ddepth, const float* dL_dalpha, void* scratch, const SrGrads* grads,
-                void* hip_stream) {
+                long long instances, long long instances_rendered, const void* image, const int* radii,
+                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                const SrGrads* grads, void* hip_stream) {
     SR_TRY(validate(view, splats));
     if (!geom || !binning || !image || !dL_dcolor || !scratch || !grads) return fail("null buffer");
     if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
@@ -241,8 +241,13 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     SR_TRY(check_hip(hipMemsetAsync(reached, 0, n_inst, st), "clear reached flags"));
     {
         StageTimer t_(5, st);
-        const char* sel = getenv("SPLATRASTER_BWD");   // "wave": round 1's pixel-per-lane kernel (kept for A/B measurements)
-        const bool wave_kernel = sel && std::string(sel) == "wave";
+        // Two kernels, one slot format.  Entry-per-lane (MFMA moment reduction) wins while a splat reaches few pixels of a tile
+        // (measured on MI355X, 800x800: 0.286 vs 0.370 ms at 2.3 instances per splat, 0.207 vs 0.215 at 4.6); pixel-per-lane
+        // (wave butterflies) wins once most lanes of an 8x8 sub-tile are inside the footprint (0.192 vs 0.203 at 7.4, 0.182 vs
+        // 0.203 at 15).  SPLATRASTER_BWD=wave|mfma pins one of them (A/B measurements).
+        const char* sel = getenv("SPLATRASTER_BWD");
+        const bool dense = instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N;
+        const bool wave_kernel = sel ? std::string(sel) == "wave" : dense;
         if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
         else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
     }

@@ -278,7 +278,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.capacity), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col), p(d_rest))
-            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
+            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity, ctx.instances,
                                        _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
                                        _ptr(scratch), C.byref(grads), stream))
         # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings

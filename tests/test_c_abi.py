@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.sr_version() == 1
+    assert lib.sr_version() == 2
     g1, g2 = lib.sr_geom_bytes(1000, 64, 64), lib.sr_geom_bytes(2000, 64, 64)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.sr_binning_bytes(1000, 64, 64) >= 1000 * 28  # ent 8 + merge ping-pong 2 x 8 + sorted ids 4 bytes per instance

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""SURVEY.md section 8f row 4, "first measure": how much of a 4-D (Owlii-style) training step is the SplatFields deform
+network, and how much the rasterizer?
+
+The network below is a SHAPE-FAITHFUL STAND-IN written for this measurement (the reference's code cannot travel to the GPU
+box): the structure of reference utils/time_utils.py:305-508 (`SplatFields`: tri-plane encoder -> refine MLP; time
+embedding; six `GeneralMLP`s: deform 128x6, rgb 128x6, flow 128x6 + head, scale 64x4, opacity 64x4, rotation 64x3, skip
+connections, NeRF positional encodings), of scene/tripFields.py:383-436 (`VarTriPlaneEncoder`: three 16-channel planes
+produced every step by a small CNN decoder from an 8-channel 20x20 noise tensor, sampled with `grid_sample`) and of
+utils/resfields.py:378-405 (ResField linear layers: weight = base + per-frame low-rank delta).  Random weights, synthetic
+points -- only the cost matters.  Runs on PyTorch-ROCm (rocBLAS / hipBLASLt / MIOpen), fp32 like the reference.
+
+Prints one JSON object: ms per forward+backward of the network for N splats, of the rasterizer (precomputed-colour path,
+reference train.py:80-81) for the same N, and the network's share of the step."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def posenc(x, multires):
+    if multires <= 0:
+        return x
+    freqs = 2.0 ** torch.arange(multires, device=x.device, dtype=x.dtype)
+    xb = x[..., None, :] * freqs[:, None]
+    return torch.cat([x, torch.sin(xb).flatten(-2), torch.cos(xb).flatten(-2)], dim=-1)
+
+
+class ResLinear(nn.Module):
+    """weight(frame) = W + (coef[frame] @ basis).view(out, in)   (reference utils/resfields.py, 'vm'-style low-rank residual)"""
+
+    def __init__(self, fin, fout, rank, n_frames):
+        super().__init__()
+        self.lin = nn.Linear(fin, fout)
+        self.rank = rank if n_frames > 0 else 0
+        if self.rank:
+            self.coef = nn.Parameter(0.01 * torch.randn(n_frames, rank))
+            self.basis = nn.Parameter(0.01 * torch.randn(rank, fout * fin))
+
+    def forward(self, x, frame_id):
+        w = self.lin.weight
+        if self.rank:
+            w = w + (self.coef[frame_id] @ self.basis).view_as(w)
+        return F.linear(x, w, self.lin.bias)
+
+
+class GeneralMLP(nn.Module):
+    def __init__(self, in_features, out_features, hidden, depth, skips, multires, rank, n_frames):
+        super().__init__()
+        self.multires, self.skips = multires, set(skips)
+        d_in = in_features + 3 * 2 * multires           # the xyz part is positionally encoded
+        self.d_in = d_in
+        dims = [d_in] + [hidden] * depth
+        self.layers = nn.ModuleList()
+        for i in range(depth):
+            fin = dims[i] + (d_in if i in self.skips else 0)
+            self.layers.append(ResLinear(fin, hidden, rank, n_frames))
+        self.out = ResLinear(hidden, out_features, rank, n_frames)
+
+    def forward(self, xyz, feat, frame_id):
+        h0 = torch.cat([posenc(xyz, self.multires), feat], dim=-1)
+        h = h0
+        for i, layer in enumerate(self.layers):
+            if i in self.skips:
+                h = torch.cat([h, h0], dim=-1)
+            h = F.leaky_relu(layer(h, frame_id))
+        return self.out(h, frame_id)
+
+
+class PlaneDecoder(nn.Module):
+    """8 x 20 x 20 noise -> 16 x 160 x 160 plane (three nearest-upsampling conv blocks), cf. Tensorial2D / Decoder"""
+
+    def __init__(self, in_ch=8, out_ch=16):
+        super().__init__()
+        chans = [in_ch, 128, 128, 64, 32]
+        self.convs = nn.ModuleList([nn.Conv2d(chans[i], chans[i + 1], 3, padding=1) for i in range(4)])
+        self.last = nn.Conv2d(32, out_ch, 3, padding=1)
+        self.register_buffer("noise", torch.randn(1, in_ch, 20, 20))
+
+    def forward(self):
+        h = self.noise
+        for i, c in enumerate(self.convs):
+            h = F.leaky_relu(c(h))
+            if i >= 1:
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+        return self.last(h)
+
+
+class SplatFieldsStandIn(nn.Module):
+    def __init__(self, n_frames=50, rank=10, time_multires=3):
+        super().__init__()
+        self.n_frames = n_frames
+        self.planes = nn.ModuleList([PlaneDecoder() for _ in range(3)])
+        fd = 48
+        self.refine = nn.Sequential(nn.Linear(fd, fd), nn.ReLU(), nn.Linear(fd, fd))
+        self.time_multires = time_multires
+        tch = 1 + 2 * time_multires
+        fin = 3 + fd + tch
+        mk = lambda out, w, d, skips, mr: GeneralMLP(fin, out, w, d, skips, mr, rank, n_frames)
+        self.mlp_deform, self.mlp_rgb, self.mlp_flow = mk(3, 128, 6, [3], 6), mk(3, 128, 6, [3], 6), mk(128, 128, 6, [3], 6)
+        self.mlp_scale, self.mlp_opacity, self.mlp_rotation = mk(3, 64, 4, [2], 4), mk(1, 64, 4, [2], 3), mk(4, 64, 3, [20], 3)
+        self.flow_head = nn.Linear(128, 6)   # se3 flow head: axis-angle + translation
+
+    def forward(self, xyz, t):
+        frame_id = int(round(float(t) * (self.n_frames - 1)))
+        planes = torch.cat([p() for p in self.planes], dim=0)                                  # [3, 16, 160, 160]
+        coord = torch.stack([xyz[None, :, [0, 1]], xyz[None, :, [1, 2]], xyz[None, :, [2, 0]]])  # [3, 1, N, 2]
+        feat = F.grid_sample(planes, coord, align_corners=False)                                # [3, 16, 1, N]
+        feat = self.refine(feat.permute(2, 3, 0, 1).reshape(xyz.shape[0], -1))
+        tt = posenc(torch.full((xyz.shape[0], 1), float(t), device=xyz.device), self.time_multires)
+        h = torch.cat([feat, tt], dim=-1)
+        xyz_can = xyz + self.mlp_deform(xyz, h, frame_id)
+        flow = self.flow_head(self.mlp_flow(xyz_can, h, frame_id))
+        return {"means3D": xyz_can + flow[:, 3:], "scales": self.mlp_scale(xyz_can, h, frame_id),
+                "opacity": torch.sigmoid(self.mlp_opacity(xyz_can, h, frame_id)),
+                "rotations": F.normalize(self.mlp_rotation(xyz_can, h, frame_id), dim=-1),
+                "rgb": torch.sigmoid(self.mlp_rgb(xyz_can, h, frame_id))}
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--splats", type=int, default=100_000)   # run_owlii.sh:7 --num_pts 100000
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd.synthetic import make_camera, make_upstream_grads
+    n, H, W = a.splats, a.size, a.size
+    net = SplatFieldsStandIn().to(dev)
+    n_params = sum(p.numel() for p in net.parameters())
+    xyz = (torch.rand(n, 3, device=dev) * 2 - 1).requires_grad_(True)
+    base_scale = torch.full((n, 3), 0.35 * n ** (-1 / 3), device=dev)
+    cam = make_camera(1, W, H, device=dev)
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.ones(3, device=dev), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False)
+
+    def net_step():
+        net.zero_grad(set_to_none=True)
+        xyz.grad = None
+        out = net(xyz, 0.37)
+        loss = sum((v * v).mean() for v in out.values())
+        loss.backward()
+
+    def raster_step(out=None):
+        if out is None:
+            with torch.no_grad():
+                out = {k: v.detach() for k, v in net(xyz, 0.37).items()}
+            out = {k: v.requires_grad_(True) for k, v in out.items()}
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=out["means3D"], means2D=torch.zeros_like(out["means3D"], requires_grad=True), opacities=out["opacity"],
+            colors_precomp=out["rgb"], scales=base_scale + 0.01 * out["scales"], rotations=out["rotations"])
+        torch.autograd.backward((color, depth, alpha), (gi, gd, ga))
+
+    with torch.no_grad():
+        fixed = {k: v.detach() for k, v in net(xyz, 0.37).items()}
+
+    def raster_only():
+        raster_step({k: v.clone().requires_grad_(True) for k, v in fixed.items()})
+
+    def full_step():
+        net.zero_grad(set_to_none=True)
+        xyz.grad = None
+        raster_step(net(xyz, 0.37))
+
+    res = {"splats": n, "image": [H, W], "net_parameters": n_params, "dtype": "fp32",
+           "net_fwd_bwd_ms": timed(net_step, a.steps, 5), "rasterizer_fwd_bwd_ms": timed(raster_only, a.steps, 5),
+           "full_step_ms": timed(full_step, a.steps, 5)}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        res["net_fwd_bwd_ms_bf16_autocast"] = timed(net_step, a.steps, 5)
+    res["net_share_of_step"] = res["net_fwd_bwd_ms"] / (res["net_fwd_bwd_ms"] + res["rasterizer_fwd_bwd_ms"])
+    macs = sum(l.lin.weight.numel() for m in net.modules() if isinstance(m, GeneralMLP) for l in list(m.layers) + [m.out])
+    res["mlp_macs_per_splat"] = macs + 2 * 48 * 48
+    res["mlp_tflops_fwd_bwd_achieved"] = 3 * 2 * res["mlp_macs_per_splat"] * n / (res["net_fwd_bwd_ms"] * 1e-3) / 1e12
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
