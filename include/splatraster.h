@@ -5,7 +5,9 @@
  *
  * Every entry point takes plain pointers and sizes; no torch / C++ types cross this boundary.
  * All device memory (inputs, outputs, gradients, the three opaque state buffers) is owned by
- * the caller (PyTorch-ROCm tensors, `tensor.data_ptr()`); the library owns nothing persistent.
+ * the caller (PyTorch-ROCm tensors, `tensor.data_ptr()`); the library owns nothing persistent (its only state: a pinned
+ * read-back word + event per host thread and device, the mutex-guarded event list of the optional stage profiling, and
+ * per-device "attribute set" flags of three kernels).
  * Every kernel is launched on the caller-supplied HIP stream.  Functions return 0 on success,
  * a non-zero status otherwise; `sr_last_error()` returns a thread-local message.
  *
@@ -130,7 +132,8 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
 /* Both forward stages in one call WITHOUT draining the pipeline: stage 1 is launched, the instance count is
  * copied to pinned host memory asynchronously, stage 2 is launched right behind it for a binning buffer sized
  * for `binning_capacity` instances (every stage-2 kernel exits immediately if the count exceeds it), and only
- * then does the host wait -- for the early copy, while the GPU keeps running stage 2.
+ * then does the host wait -- for the early copy, while the GPU keeps running stage 2.  (So the host still blocks once per
+ * forward, as upstream's num_rendered read-back does, but only until stage 1 has finished: the GPU never idles.)
  * Returns 0 when the count fits (outputs valid), SR_NEED_CAPACITY when it does not: the caller then allocates
  * sr_binning_bytes(*instances_out) and calls sr_forward_render with instances = *instances_out.
  * The binning buffer is carved for the capacity it was rendered with; pass that same number as `instances`

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -22,6 +23,7 @@ int check_hip(hipError_t e, const char* what) {
 struct ProfRec { int stage; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+std::mutex g_prof_mutex;   // host threads rendering on their own streams may record concurrently
 const char* kStageNames[SR_PROFILE_STAGES] = {"preprocess", "scan", "emit", "sort_tiles", "render_forward",
                                               "render_backward", "preprocess_backward"};
 struct StageTimer {
@@ -31,9 +33,12 @@ struct StageTimer {
         ProfRec r; r.stage = stage;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         hipEventRecord(r.a, st);
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
         g_prof.push_back(r); idx = (int)g_prof.size() - 1;
+        end = r.b;
     }
-    ~StageTimer() { if (idx >= 0) hipEventRecord(g_prof[idx].b, st); }
+    hipEvent_t end = nullptr;
+    ~StageTimer() { if (idx >= 0) hipEventRecord(end, st); }
 };
 
 // Pinned word + event per (host thread, device) for the asynchronous instance-count read-back of sr_forward
@@ -368,6 +373,7 @@ int sr_debug_backward_stats(unsigned long long* out8, int reset) {
 int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 
 int sr_profile_collect(double* ms_sum, long long* launches) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
