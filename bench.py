@@ -179,9 +179,11 @@ def blend_work_counters(n, width, height, mean_scale):
 
 def valu_roofline(workload: dict, stage_ms: dict):
     """Issue-side roofline of the two blend kernels from the committed SQ counter passes (profiles/pmc_sq.json, rocprofv3
-    --pmc, per-launch averages): wave-level VALU / SALU instruction counts and the share of the launch during which the
-    SIMDs' VALU was busy (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles).  The counters are a recorded
-    measurement of this workload; the launch duration next to them is the live one."""
+    --pmc, per-launch averages): wave-level VALU / SALU / LDS / MFMA instruction counts and the kernel cycles per wave-VALU
+    instruction per SIMD (kernel cycles = SQ_BUSY_CYCLES / 32 shader engines).  `frac` relates that to the densest issue rate
+    measured in this pipeline (3.7 cycles per instruction per SIMD: the forward blend and round 1's backward blend, whose
+    VALU pipes are saturated).  The counters are a recorded measurement of this workload; the launch duration next to them
+    is the live one."""
     path = os.path.join(ROOT, "profiles", "pmc_sq.json")
     if not os.path.exists(path):
         return None
@@ -191,7 +193,7 @@ def valu_roofline(workload: dict, stage_ms: dict):
         return None
     if pj.get("_workload") != workload:
         return None
-    out = {"source": pj.get("_source"), "simds": 1024}
+    out = {"source": pj.get("_source"), "simds": 1024, "issue_bound_cycles_per_valu_inst_per_simd": 3.7}
     for stage in ("render_forward", "render_backward"):
         c = pj.get(stage)
         if not c:
@@ -199,8 +201,8 @@ def valu_roofline(workload: dict, stage_ms: dict):
         cycles = c["SQ_BUSY_CYCLES"] / 32.0            # summed over the 32 shader engines
         out[stage] = {"wave_valu_insts_per_launch": c["SQ_INSTS_VALU"], "wave_salu_insts_per_launch": c["SQ_INSTS_SALU"],
                       "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "mfma_insts_per_launch": c.get("SQ_INSTS_MFMA"),
-                      "kernel_cycles": cycles, "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles,
-                      "cycles_per_valu_inst_per_simd": cycles * 1024.0 / c["SQ_INSTS_VALU"],
+                      "kernel_cycles": cycles, "cycles_per_valu_inst_per_simd": cycles * 1024.0 / c["SQ_INSTS_VALU"],
+                      "frac": min(1.0, 3.7 / (cycles * 1024.0 / c["SQ_INSTS_VALU"])),
                       "live_avg_launch_ms": stage_ms.get(stage)}
     return out
 
