@@ -204,12 +204,7 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0,
     (void)lane;
 }
 
-#ifdef SR_BWD_WPE
-#define SR_BWD_ATTR __attribute__((amdgpu_waves_per_eu(SR_BWD_WPE, SR_BWD_WPE)))
-#else
-#define SR_BWD_ATTR
-#endif
-__global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im,
+__global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im,
                                                                  const float* __restrict__ dL_dcolor,
                                                                  const float* __restrict__ dL_ddepth,
                                                                  const float* __restrict__ dL_dalpha,
@@ -376,7 +371,6 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
         __syncthreads();
         SR_PHASE(4);   // barrier after (C)
         // ---------------- (D) replay: each wavefront walks the buckets of its four quads ----------------
-#ifndef SR_BWD_SKIP_REPLAY
         // Quads are handed out through an LDS ticket (which wavefront replays which quad does not reach the results: every
         // quad's sums go to its own slots and are combined in a fixed order).  The next ticket is drawn one quad ahead.
         uint32_t ticket = 0u;
@@ -467,7 +461,6 @@ __global__ void __launch_bounds__(kBlock) SR_BWD_ATTR k_render_backward_mfma(con
                 }
             }
         }
-#endif
         SR_PHASE(5);   // (D) replay
         __syncthreads();
         SR_PHASE(6);   // barrier after (D)
