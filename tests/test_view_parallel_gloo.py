@@ -103,3 +103,39 @@ def test_allreduce_gradients_averages():
         p.join(60)
     for o in outs:
         assert torch.equal(torch.from_numpy(o), torch.full((5,), 1.5))
+
+
+def _ragged_worker(rank, world, port, q):
+    """rank 1 has no gradient for one parameter (it rendered no view that reached it) and only the leading SH bands carry
+    gradient: every rank must still issue the same collectives (zero-filled), and only the active bands travel."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    means = torch.nn.Parameter(torch.zeros(6, 3))
+    opac = torch.nn.Parameter(torch.zeros(6, 1))
+    shs = torch.nn.Parameter(torch.zeros(6, 16, 3))
+    means.grad = torch.full((6, 3), float(rank + 1))
+    if rank == 0:
+        opac.grad = torch.full((6, 1), 4.0)          # rank 1: opac.grad stays None
+    shs.grad = torch.zeros(6, 16, 3)
+    shs.grad[:, :4] = float(10 * (rank + 1))          # active_sh_degree = 1: bands 4..15 are exactly zero everywhere
+    allreduce_gradients([means, opac, shs], world, sh_param=shs, sh_active_coeffs=4)
+    q.put((means.grad.numpy().copy(), opac.grad.numpy().copy(), shs.grad.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_allreduce_gradients_with_missing_grads_and_active_sh_bands():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for m, o, s in outs:
+        assert torch.equal(torch.from_numpy(m), torch.full((6, 3), 1.5))
+        assert torch.equal(torch.from_numpy(o), torch.full((6, 1), 2.0))          # (4 + 0) / 2
+        s = torch.from_numpy(s)
+        assert torch.equal(s[:, :4], torch.full((6, 4, 3), 15.0)) and (s[:, 4:] == 0).all()
