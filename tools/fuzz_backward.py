@@ -16,11 +16,12 @@ from tests.helpers import grad_error, make_scene, run_hip  # noqa: E402
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"   # larger clouds and images
     dev = torch.device("cuda:0")
     worst, bad = 0.0, 0
     for it in range(cases):
-        n = int(math.exp(rnd.uniform(0, math.log(30000))))
-        w, h = rnd.randint(5, 330), rnd.randint(5, 270)
+        n = int(math.exp(rnd.uniform(0, math.log(400000 if big else 30000))))
+        w, h = (rnd.randint(100, 1000), rnd.randint(100, 900)) if big else (rnd.randint(5, 330), rnd.randint(5, 270))
         scale = math.exp(rnd.uniform(math.log(0.003), math.log(0.5)))
         use_sh = rnd.random() < 0.6
         wd, wa = rnd.random() < 0.7, rnd.random() < 0.7
