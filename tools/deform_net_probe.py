@@ -142,8 +142,12 @@ def main():
     ap.add_argument("--splats", type=int, default=100_000)   # run_owlii.sh:7 --num_pts 100000
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: MIOpen searches a solver per convolution shape instead of its "
+                         "immediate-mode fallback (the naive direct kernels of the tri-plane decoder)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
     from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from splatfields_amd.synthetic import make_camera, make_upstream_grads
     n, H, W = a.splats, a.size, a.size
@@ -184,7 +188,7 @@ def main():
         xyz.grad = None
         raster_step(net(xyz, 0.37))
 
-    res = {"splats": n, "image": [H, W], "net_parameters": n_params, "dtype": "fp32",
+    res = {"splats": n, "image": [H, W], "net_parameters": n_params, "dtype": "fp32", "miopen_find": bool(a.miopen_find),
            "net_fwd_bwd_ms": timed(net_step, a.steps, 5), "rasterizer_fwd_bwd_ms": timed(raster_only, a.steps, 5),
            "full_step_ms": timed(full_step, a.steps, 5)}
     with torch.autocast("cuda", dtype=torch.bfloat16):
