@@ -150,6 +150,9 @@ int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
     if (hs) {
         SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));
         max_len = (long long)hs->pinned[1];
+        // the binning buffer is too small: the scatter just launched exits on its own, and nothing else of stage 2 is worth
+        // launching -- the caller re-runs it with a buffer that fits (SR_NEED_CAPACITY)
+        if ((long long)hs->pinned[0] > (long long)b.capacity) return 0;
     }
     { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, max_len, st); }
     SR_TRY(after_launch(view, st, "sort_tiles"));
