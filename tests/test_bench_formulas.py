@@ -25,3 +25,20 @@ def test_stage_bytes_are_positive_and_scale_with_their_units():
     # the blend kernels move 44 / 88 bytes per instance + 28 bytes per pixel
     assert bench.stage_bytes("render_forward", 0, 0, 10, 0, 12) == 440 and bench.stage_bytes("render_backward", 0, 0, 10, 0, 12) == 880
     assert bench.stage_bytes("render_forward", 0, 0, 0, 10, 12) == 280
+
+
+def test_roofline_valu_is_reproducible_from_the_committed_counters():
+    """bench.py's issue-side roofline comes from profiles/pmc_sq.json (rocprofv3 SQ counter passes): pure arithmetic."""
+    import json
+    wl = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))["_workload"]
+    r = bench.valu_roofline(wl, {"render_forward": 0.12, "render_backward": 0.28})
+    assert r is not None and r["simds"] == 1024
+    for stage in ("render_forward", "render_backward"):
+        s = r[stage]
+        assert s["wave_valu_insts_per_launch"] > 1e7 and s["kernel_cycles"] > 1e5
+        assert abs(s["cycles_per_valu_inst_per_simd"] - s["kernel_cycles"] * 1024 / s["wave_valu_insts_per_launch"]) < 1e-9
+        assert 0.0 < s["frac"] <= 1.0
+    # the entry-per-lane backward issues fewer instructions than the forward has per launch x 2, at a lower issue rate
+    assert r["render_backward"]["mfma_insts_per_launch"] > 0 and r["render_forward"]["mfma_insts_per_launch"] == 0
+    # another workload has no recorded counters
+    assert bench.valu_roofline(dict(wl, splats=123), {}) is None
