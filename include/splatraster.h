@@ -218,6 +218,25 @@ int sr_densify_gather(int n_splats, int row_floats, const float* src, float* dst
                       const float* log_scales, int scale_cols, const float* rotations, const float* unit_normals,
                       void* hip_stream);
 
+/* Fused forward of one `GeneralMLP` of the SplatFields deform network (reference utils/time_utils.py:123-191; SURVEY.md section 8f
+ * row 4): y = act(W_L ... act(W_1 [x0 | h] + b_1) ...) for n_points points in ONE kernel, activations in registers, exact fp32
+ * MFMA.  Every layer is followed by leaky ReLU with `negative_slope` (the reference applies `act` after the last layer too;
+ * an output activation such as sigmoid / normalize is the caller's).  Layer l reads `mem_tiles` x 16 input channels from x0
+ * (row stride x0_row_floats, rows 16-byte aligned: the network input -- first layer -- or the skip connection, which the
+ * reference concatenates IN FRONT of the hidden state) followed by `reg_tiles` x 16 channels of the previous layer's output,
+ * and writes `out_tiles` x 16 channels; hidden_tiles = 4 or 8 (widths up to 64 / 128) bounds both.  Weights arrive packed for
+ * the MFMA K order (layout: csrc/mlp.hip header; packer: splatfields_amd/fused_mlp.py), biases padded to 16 * out_tiles.
+ * y is [n_points, out_features], out_features <= 16 * out_tiles of the last layer. */
+typedef struct SrMlpLayer {
+    const float* w_packed;
+    const float* bias;
+    int out_tiles;
+    int mem_tiles;   /* even */
+    int reg_tiles;   /* even; 0 for the first layer */
+} SrMlpLayer;
+int sr_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row_floats,
+                   float* y, int out_features, float negative_slope, void* hip_stream);
+
 /* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
  * (`instances` = the capacity the binning buffer was carved for):
  *   out[0]  geom:    tile_start  uint32[tiles + 1]   first list entry of every 16x16 tile (row-major tiles)

@@ -33,6 +33,10 @@ class SrGrads(C.Structure):
                 ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
+class SrMlpLayer(C.Structure):
+    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_tiles", C.c_int), ("mem_tiles", C.c_int), ("reg_tiles", C.c_int)]
+
+
 # every symbol include/splatraster.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sr_version": (C.c_int, []),
@@ -61,6 +65,8 @@ SYMBOLS = {
                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
     "sr_densify_gather": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "sr_mlp_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SrMlpLayer), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                 C.c_void_p]),
     "sr_debug_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_size_t)]),
     "sr_debug_backward_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sr_profile_enable": (C.c_int, [C.c_int]),

@@ -354,6 +354,17 @@ int sr_densify_gather(int n, int row_floats, const float* src, float* dst, const
     return check_hip(hipGetLastError(), "densify_gather");
 }
 
+int sr_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row_floats,
+                   float* y, int out_features, float negative_slope, void* hip_stream) {
+    if (n_points < 0 || !layers || (n_points > 0 && (!x0 || !y))) return fail("bad arguments to sr_mlp_forward");
+    if (x0_row_floats <= 0 || (x0_row_floats & 3) || (reinterpret_cast<uintptr_t>(x0) & 15u)) return fail("sr_mlp_forward: x0 rows must be 16-byte aligned");
+    if (!(negative_slope >= 0.0f && negative_slope < 1.0f)) return fail("sr_mlp_forward: negative_slope must be in [0, 1)");
+    if (sr::launch_mlp_forward(n_points, hidden_tiles, n_layers, layers, x0, x0_row_floats, y, out_features, negative_slope,
+                               static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_mlp_forward: unsupported layer description (hidden_tiles 4 or 8, <= 12 layers, even tile counts)");
+    return check_hip(hipGetLastError(), "mlp_forward");
+}
+
 int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {
     if (!out4 || n < 0 || h <= 0 || w <= 0 || instances < 0) return fail("bad arguments to sr_debug_layout");
     sr::Geom g; sr::Binning b;

@@ -53,6 +53,10 @@ void launch_densify_plan(int n, const float* log_scales, int scale_cols, const f
 void launch_densify_gather(int n, int row, const float* src, float* dst, const int32_t* dest, int mode, const float* log_scales,
                            int scale_cols, const float* rotations, const float* unit, hipStream_t st);
 
+// mlp.hip
+int launch_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row,
+                       float* y, int out_features, float slope, hipStream_t st);
+
 // knn.hip
 size_t knn_workspace_bytes(int n);
 void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream_t st);

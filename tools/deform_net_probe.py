@@ -66,6 +66,34 @@ class GeneralMLP(nn.Module):
             self.layers.append(ResLinear(fin, hidden, rank, n_frames))
         self.out = ResLinear(hidden, out_features, rank, n_frames)
 
+    def effective_weights(self, frame_id):
+        ws, bs = [], []
+        for layer in list(self.layers) + [self.out]:
+            w = layer.lin.weight
+            if layer.rank:
+                w = w + (layer.coef[frame_id] @ layer.basis).view_as(w)
+            ws.append(w.detach().contiguous()); bs.append(layer.lin.bias.detach())
+        return ws, bs
+
+    def forward_fused(self, xyz, feat, frame_id):
+        """the same network through splatfields_amd.fused_mlp (one kernel for all layers; inference only).  Note the layer
+        order of this stand-in: the skip input is concatenated BEHIND the hidden state here, in front of it in the reference
+        -- the fused kernel implements the reference's order, so the stand-in's skip weights are reordered on the way in."""
+        from splatfields_amd.fused_mlp import FusedGeneralMLP
+        key = int(frame_id)
+        if getattr(self, "_fused_key", None) != key:
+            ws, bs = self.effective_weights(frame_id)
+            hidden = ws[0].shape[0]
+            skips = []
+            for i in sorted(self.skips):
+                if 0 < i < len(ws):   # layer i consumes cat([h, h0]): move the h0 block in front
+                    ws[i] = torch.cat([ws[i][:, hidden:], ws[i][:, :hidden]], dim=1).contiguous()
+                    skips.append(i - 1)
+            self._fused = FusedGeneralMLP(ws, bs, self.d_in, skips, negative_slope=0.01)
+            self._fused_key = key
+        h0 = torch.cat([posenc(xyz, self.multires), feat], dim=-1)
+        return self._fused(h0)
+
     def forward(self, xyz, feat, frame_id):
         h0 = torch.cat([posenc(xyz, self.multires), feat], dim=-1)
         h = h0
@@ -110,20 +138,22 @@ class SplatFieldsStandIn(nn.Module):
         self.mlp_scale, self.mlp_opacity, self.mlp_rotation = mk(3, 64, 4, [2], 4), mk(1, 64, 4, [2], 3), mk(4, 64, 3, [20], 3)
         self.flow_head = nn.Linear(128, 6)   # se3 flow head: axis-angle + translation
 
-    def forward(self, xyz, t):
+    def forward(self, xyz, t, fused=False):
         frame_id = int(round(float(t) * (self.n_frames - 1)))
+        run = (lambda m, x, h, f: m.forward_fused(x, h, f)) if fused else (lambda m, x, h, f: F.leaky_relu(m(x, h, f)))
         planes = torch.cat([p() for p in self.planes], dim=0)                                  # [3, 16, 160, 160]
         coord = torch.stack([xyz[None, :, [0, 1]], xyz[None, :, [1, 2]], xyz[None, :, [2, 0]]])  # [3, 1, N, 2]
         feat = F.grid_sample(planes, coord, align_corners=False)                                # [3, 16, 1, N]
         feat = self.refine(feat.permute(2, 3, 0, 1).reshape(xyz.shape[0], -1))
         tt = posenc(torch.full((xyz.shape[0], 1), float(t), device=xyz.device), self.time_multires)
         h = torch.cat([feat, tt], dim=-1)
-        xyz_can = xyz + self.mlp_deform(xyz, h, frame_id)
-        flow = self.flow_head(self.mlp_flow(xyz_can, h, frame_id))
-        return {"means3D": xyz_can + flow[:, 3:], "scales": self.mlp_scale(xyz_can, h, frame_id),
-                "opacity": torch.sigmoid(self.mlp_opacity(xyz_can, h, frame_id)),
-                "rotations": F.normalize(self.mlp_rotation(xyz_can, h, frame_id), dim=-1),
-                "rgb": torch.sigmoid(self.mlp_rgb(xyz_can, h, frame_id))}
+        # as in the reference, the activation follows every layer of a GeneralMLP, the last one included (time_utils.py:185-186)
+        xyz_can = xyz + run(self.mlp_deform, xyz, h, frame_id)
+        flow = self.flow_head(run(self.mlp_flow, xyz_can, h, frame_id))
+        return {"means3D": xyz_can + flow[:, 3:], "scales": run(self.mlp_scale, xyz_can, h, frame_id),
+                "opacity": torch.sigmoid(run(self.mlp_opacity, xyz_can, h, frame_id)),
+                "rotations": F.normalize(run(self.mlp_rotation, xyz_can, h, frame_id), dim=-1),
+                "rgb": torch.sigmoid(run(self.mlp_rgb, xyz_can, h, frame_id))}
 
 
 def timed(fn, steps, warmup):
@@ -193,6 +223,14 @@ def main():
            "full_step_ms": timed(full_step, a.steps, 5)}
     with torch.autocast("cuda", dtype=torch.bfloat16):
         res["net_fwd_bwd_ms_bf16_autocast"] = timed(net_step, a.steps, 5)
+    # inference (rendering a trained 4-D model, reference render.py): forward only, PyTorch layers vs the fused MLP kernel
+    with torch.no_grad():
+        ref_out = net(xyz, 0.37)
+        fused_out = net(xyz, 0.37, fused=True)
+        res["fused_forward_max_rel_diff"] = max(((ref_out[k] - fused_out[k]).abs().max() / ref_out[k].abs().max().clamp_min(1e-12)).item()
+                                                for k in ref_out)
+        res["net_forward_ms"] = timed(lambda: net(xyz, 0.37), a.steps, 5)
+        res["net_forward_fused_mlps_ms"] = timed(lambda: net(xyz, 0.37, fused=True), a.steps, 5)
     res["net_share_of_step"] = res["net_fwd_bwd_ms"] / (res["net_fwd_bwd_ms"] + res["rasterizer_fwd_bwd_ms"])
     macs = sum(l.lin.weight.numel() for m in net.modules() if isinstance(m, GeneralMLP) for l in list(m.layers) + [m.out])
     res["mlp_macs_per_splat"] = macs + 2 * 48 * 48
