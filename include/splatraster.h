@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define SR_VERSION 2
+#define SR_VERSION 3
 #define SR_TILE 16 /* binning tile edge in pixels (upstream BLOCK_X = BLOCK_Y) */
 
 typedef struct SrView {
@@ -218,24 +218,91 @@ int sr_densify_gather(int n_splats, int row_floats, const float* src, float* dst
                       const float* log_scales, int scale_cols, const float* rotations, const float* unit_normals,
                       void* hip_stream);
 
-/* Fused forward of one `GeneralMLP` of the SplatFields deform network (reference utils/time_utils.py:123-191; SURVEY.md section 8f
- * row 4): y = act(W_L ... act(W_1 [x0 | h] + b_1) ...) for n_points points in ONE kernel, activations in registers, exact fp32
- * MFMA.  Every layer is followed by leaky ReLU with `negative_slope` (the reference applies `act` after the last layer too;
- * an output activation such as sigmoid / normalize is the caller's).  Layer l reads `mem_tiles` x 16 input channels from x0
- * (row stride x0_row_floats, rows 16-byte aligned: the network input -- first layer -- or the skip connection, which the
- * reference concatenates IN FRONT of the hidden state) followed by `reg_tiles` x 16 channels of the previous layer's output,
- * and writes `out_tiles` x 16 channels; hidden_tiles = 4 or 8 (widths up to 64 / 128) bounds both.  Weights arrive packed for
- * the MFMA K order (layout: csrc/mlp.hip header; packer: splatfields_amd/fused_mlp.py), biases padded to 16 * out_tiles.
- * y is [n_points, out_features], out_features <= 16 * out_tiles of the last layer. */
-typedef struct SrMlpLayer {
+/* Fused MLP chains of the SplatFields deform network's `GeneralMLP`s (reference utils/time_utils.py:123-191; SURVEY.md
+ * section 8f row 4): n_points points are carried through a list of OPS in ONE kernel, the running state (<= 16 * hidden_tiles
+ * channels per point) in registers, exact fp32 MFMA.  An op applies one packed matrix to [mem_tiles x 16 channels read from
+ * `src` (row stride src_row floats, rows 16-byte aligned) | reg_tiles x 16 channels of the running state], starting from
+ * `bias` (or 0), and produces out_tiles x 16 channels, which then go through `epilogue`:
+ *   SR_MLP_LEAKY  leaky ReLU with negative_slope         -- a forward layer: y = act(W [x0 | h] + b); the reference
+ *                 concatenates the skip input IN FRONT of the hidden state, hence memory channels first;
+ *   SR_MLP_MASK   times leaky'(.) read off the sign of `mask` (the saved activation of the layer below, row stride mask_row)
+ *                 -- a backward step: dZ_below = (W_hidden^T dZ) * act'(.);
+ *   SR_MLP_NONE   nothing.
+ * The result becomes the new running state unless keep_state != 0, and, if `store` is set, its first store_channels
+ * channels are written to (store_accumulate: added to) store[point * store_row + channel]: the saved activations / output
+ * of the forward, the dZ of every layer (for the weight-gradient GEMMs) and dL/dx0 of the backward.  hidden_tiles = 4 or 8
+ * bounds out_tiles and reg_tiles; tile counts of the inputs are even.  Matrices arrive packed for the MFMA K order (layout:
+ * csrc/mlp.hip header; packer: splatfields_amd/fused_mlp.py), biases padded to 16 * out_tiles floats.  Host side that builds
+ * the forward and backward op lists of a GeneralMLP: splatfields_amd/fused_mlp.py. */
+#define SR_MLP_MAX_OPS 24
+#define SR_MLP_NONE 0
+#define SR_MLP_LEAKY 1
+#define SR_MLP_MASK 2
+typedef struct SrMlpOp {
     const float* w_packed;
-    const float* bias;
+    const float* bias;         /* may be null */
+    const float* src;          /* memory input channels (mem_tiles > 0) */
+    const float* mask;         /* SR_MLP_MASK */
+    float* store;              /* may be null */
     int out_tiles;
-    int mem_tiles;   /* even */
-    int reg_tiles;   /* even; 0 for the first layer */
-} SrMlpLayer;
-int sr_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row_floats,
-                   float* y, int out_features, float negative_slope, void* hip_stream);
+    int mem_tiles;             /* even */
+    int reg_tiles;             /* even */
+    int src_row;
+    int epilogue;
+    int mask_row;
+    int store_row;
+    int store_channels;
+    int store_accumulate;
+    int keep_state;
+} SrMlpOp;
+int sr_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float negative_slope, void* hip_stream);
+
+/* Packs matrices for sr_mlp_chain on the device (training repacks every step: the weights change, and ResField layers
+ * compose W + delta(frame) per step -- reference utils/resfields.py:378-405).  Job j builds the packed form of the matrix
+ *   A[r][c'],  r < 16 * out_tiles,  c' < mem_pad + reg_width:
+ *     c' <  mem_pad:  column c = c' of the memory block   (zero unless c < n_mem),  source column mem_col0 + c
+ *     c' >= mem_pad:  column c = c' - mem_pad of the register block (zero unless c < n_reg), source column reg_col0 + c
+ *   A[r][.] = 0 unless r < n_rows;  element = transposed ? W[column][row0 + r] : W[row0 + r][column],  W row stride `ld`
+ * (transposed jobs build the backward's W^T blocks straight from the layer's weight), and, when bias_dst is set, copies
+ * n_bias floats of bias_src to bias_dst and zero-fills it up to 16 * out_tiles.  mem_pad and reg_width are multiples of 32 / 16
+ * with an even total tile count.  dst holds 16 * out_tiles * (mem_pad + reg_width) floats, 16-byte aligned. */
+#define SR_MLP_MAX_PACK_JOBS 32
+typedef struct SrMlpPackJob {
+    const float* w;
+    const float* bias_src;     /* may be null */
+    float* dst;
+    float* bias_dst;           /* may be null */
+    int ld;
+    int transposed;
+    int row0, n_rows;
+    int n_mem, mem_pad, mem_col0;
+    int n_reg, reg_width, reg_col0;
+    int out_tiles;
+    int n_bias;
+} SrMlpPackJob;
+int sr_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, void* hip_stream);
+
+/* Weight and bias gradients of the layers of a fused MLP: for every job
+ *   dw[m * dw_row + dw_col0 + c] = sum over points p of dz[p * dz_row + m] * x[p * x_row + c],   m < job.m, c < job.k
+ *   db[m]                        = sum over points p of dz[p * dz_row + m]                       (when db is set)
+ * -- dW_l = dZ_l^T [h_in | h_{l-1}] as one job per column block, all layers of the network in ONE launch: the contraction
+ * runs over the 10^5 points and the result is tiny, which library GEMMs serialise (csrc/mlp.hip).  dz and x rows are 16-byte
+ * aligned with row strides that are multiples of 4 floats; entries of a row beyond m / k up to the row stride may hold
+ * anything finite or not (they only reach results that are dropped).  Results are written, not accumulated; the sum over the
+ * points has a fixed order (deterministic).  `workspace`: sr_mlp_weight_grad_workspace(...) bytes, 16-byte aligned. */
+#define SR_MLP_MAX_GRAD_JOBS 16
+#define SR_MLP_MAX_GRAD_TASKS 128      /* 64 x 64 blocks over all jobs */
+typedef struct SrMlpGradJob {
+    const float* dz;
+    const float* x;
+    float* dw;
+    float* db;                 /* may be null */
+    int dz_row, m;
+    int x_row, k;
+    int dw_row, dw_col0;
+} SrMlpGradJob;
+size_t sr_mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob* jobs);   /* 0 for an unsupported job list */
+int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
  * (`instances` = the capacity the binning buffer was carved for):

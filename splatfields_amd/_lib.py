@@ -33,8 +33,28 @@ class SrGrads(C.Structure):
                 ("dL_dshs", C.c_void_p), ("dL_dcolors", C.c_void_p), ("dL_dshs_rest", C.c_void_p)]
 
 
-class SrMlpLayer(C.Structure):
-    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out_tiles", C.c_int), ("mem_tiles", C.c_int), ("reg_tiles", C.c_int)]
+class SrMlpOp(C.Structure):
+    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("src", C.c_void_p), ("mask", C.c_void_p), ("store", C.c_void_p),
+                ("out_tiles", C.c_int), ("mem_tiles", C.c_int), ("reg_tiles", C.c_int), ("src_row", C.c_int), ("epilogue", C.c_int),
+                ("mask_row", C.c_int), ("store_row", C.c_int), ("store_channels", C.c_int), ("store_accumulate", C.c_int),
+                ("keep_state", C.c_int)]
+
+
+class SrMlpPackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias_src", C.c_void_p), ("dst", C.c_void_p), ("bias_dst", C.c_void_p), ("ld", C.c_int),
+                ("transposed", C.c_int), ("row0", C.c_int), ("n_rows", C.c_int), ("n_mem", C.c_int), ("mem_pad", C.c_int),
+                ("mem_col0", C.c_int), ("n_reg", C.c_int), ("reg_width", C.c_int), ("reg_col0", C.c_int), ("out_tiles", C.c_int),
+                ("n_bias", C.c_int)]
+
+
+class SrMlpGradJob(C.Structure):
+    _fields_ = [("dz", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("dz_row", C.c_int), ("m", C.c_int),
+                ("x_row", C.c_int), ("k", C.c_int), ("dw_row", C.c_int), ("dw_col0", C.c_int)]
+
+
+MLP_MAX_GRAD_JOBS, MLP_MAX_GRAD_TASKS = 16, 128
+MLP_MAX_PACK_JOBS = 32
+MLP_MAX_OPS, MLP_NONE, MLP_LEAKY, MLP_MASK = 24, 0, 1, 2      # include/splatraster.h: SR_MLP_*
 
 
 # every symbol include/splatraster.h declares: name -> (restype, argtypes)
@@ -65,8 +85,10 @@ SYMBOLS = {
                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
     "sr_densify_gather": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
-    "sr_mlp_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SrMlpLayer), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
-                                 C.c_void_p]),
+    "sr_mlp_pack": (C.c_int, [C.c_int, C.POINTER(SrMlpPackJob), C.c_void_p]),
+    "sr_mlp_weight_grad_workspace": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob)]),
+    "sr_mlp_weight_grad": (C.c_int, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sr_mlp_chain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SrMlpOp), C.c_float, C.c_void_p]),
     "sr_debug_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_size_t)]),
     "sr_debug_backward_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sr_profile_enable": (C.c_int, [C.c_int]),

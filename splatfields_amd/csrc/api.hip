@@ -354,15 +354,34 @@ int sr_densify_gather(int n, int row_floats, const float* src, float* dst, const
     return check_hip(hipGetLastError(), "densify_gather");
 }
 
-int sr_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row_floats,
-                   float* y, int out_features, float negative_slope, void* hip_stream) {
-    if (n_points < 0 || !layers || (n_points > 0 && (!x0 || !y))) return fail("bad arguments to sr_mlp_forward");
-    if (x0_row_floats <= 0 || (x0_row_floats & 3) || (reinterpret_cast<uintptr_t>(x0) & 15u)) return fail("sr_mlp_forward: x0 rows must be 16-byte aligned");
-    if (!(negative_slope >= 0.0f && negative_slope < 1.0f)) return fail("sr_mlp_forward: negative_slope must be in [0, 1)");
-    if (sr::launch_mlp_forward(n_points, hidden_tiles, n_layers, layers, x0, x0_row_floats, y, out_features, negative_slope,
-                               static_cast<hipStream_t>(hip_stream)))
-        return fail("sr_mlp_forward: unsupported layer description (hidden_tiles 4 or 8, <= 12 layers, even tile counts)");
-    return check_hip(hipGetLastError(), "mlp_forward");
+int sr_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float negative_slope, void* hip_stream) {
+    if (n_points < 0 || !ops) return fail("bad arguments to sr_mlp_chain");
+    if (!(negative_slope >= 0.0f && negative_slope < 1.0f)) return fail("sr_mlp_chain: negative_slope must be in [0, 1)");
+    if (sr::launch_mlp_chain(n_points, hidden_tiles, n_ops, ops, negative_slope, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_mlp_chain: unsupported op list (hidden_tiles 4 or 8, <= SR_MLP_MAX_OPS ops, even input tile counts, "
+                    "16-byte aligned rows wide enough for the tiles read)");
+    return check_hip(hipGetLastError(), "mlp_chain");
+}
+
+int sr_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, void* hip_stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail("bad arguments to sr_mlp_pack");
+    if (sr::launch_mlp_pack(n_jobs, jobs, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_mlp_pack: unsupported job (<= SR_MLP_MAX_PACK_JOBS jobs; mem_pad multiple of 32, reg_width of 16, even tile "
+                    "count; counts within their padded sizes; 16-byte aligned destination)");
+    return check_hip(hipGetLastError(), "mlp_pack");
+}
+
+size_t sr_mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob* jobs) {
+    if (!jobs) return 0;
+    return sr::mlp_weight_grad_workspace(n_points, n_jobs, jobs);
+}
+
+int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (!jobs || n_points < 1) return fail("bad arguments to sr_mlp_weight_grad");
+    if (sr::launch_mlp_weight_grad(n_points, n_jobs, jobs, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_mlp_weight_grad: unsupported job list (<= SR_MLP_MAX_GRAD_JOBS jobs, <= SR_MLP_MAX_GRAD_TASKS 64x64 blocks, "
+                    "16-byte aligned rows with strides that are multiples of 4) or workspace too small");
+    return check_hip(hipGetLastError(), "mlp_weight_grad");
 }
 
 int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {

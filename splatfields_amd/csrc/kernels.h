@@ -54,8 +54,10 @@ void launch_densify_gather(int n, int row, const float* src, float* dst, const i
                            int scale_cols, const float* rotations, const float* unit, hipStream_t st);
 
 // mlp.hip
-int launch_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row,
-                       float* y, int out_features, float slope, hipStream_t st);
+size_t mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob* jobs);
+int launch_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, hipStream_t st);
+int launch_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, hipStream_t st);
+int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float slope, hipStream_t st);
 
 // knn.hip
 size_t knn_workspace_bytes(int n);

@@ -1,10 +1,11 @@
-// Fused forward of the small MLPs of the SplatFields deform network for gfx950.
+// Fused MLP chains of the SplatFields deform network for gfx950: forward, and the
+// activation-gradient chain of the backward.
 //
-// What it replaces: the forward of reference utils/time_utils.py:123-191 (`GeneralMLP`: Linear -> activation for every
-// layer, the input concatenated back in front of the hidden state after the `skips` layers), which PyTorch-ROCm runs as
-// one GEMM + several elementwise kernels per layer with every activation round-tripping through HBM (DESIGN.md section 8:
-// the network is 98 % of a 4-D step).  Here a workgroup carries 128 points through ALL layers: activations never leave
-// the registers, weights stream through LDS once per 128 points.
+// What it replaces: reference utils/time_utils.py:123-191 (`GeneralMLP`: Linear -> activation for every layer, the
+// input concatenated back in front of the hidden state after the `skips` layers), which PyTorch-ROCm runs as one GEMM +
+// several elementwise kernels per layer with every activation round-tripping through HBM (the
+// network is 98 % of a 4-D step).  Here a workgroup carries 128 points through ALL layers: activations never leave the
+// registers, weights stream through LDS once per 128 points.
 //
 // MI355X mapping: Y^T[out x points] = W[out x in] . X^T[in x points] on `v_mfma_f32_16x16x4_f32` (exact fp32 fma chains),
 // points in the N dimension (lanes n = lane & 15), so the accumulator of one layer -- lane (k, n), tile t, register i =
@@ -13,9 +14,16 @@
 // Bias is the accumulator's initial value, the activation a per-register operation.  A wavefront holds 2 x 16 points;
 // a workgroup's 4 wavefronts share the weight chunks (2 channel tiles = 32 input channels at a time, double-buffered).
 //
-// Packed weights of a layer with MT output tiles and KT input tiles (host side: splatfields_amd/fused_mlp.py):
-//   float index ((((c * MT + mt) * 2 + tl) * 64 + lane) * 4 + i)  =  W[16 mt + (lane & 15)][16 (2 c + tl) + 4 (lane >> 4) + i]
-// (zero beyond the layer's true sizes), bias padded to 16 MT floats.
+// The kernel executes a list of OPS; an op is one matrix applied to [memory channels | the register state]:
+//   forward layer     acc = b + W [x0 | h];  h <- leaky(acc);  optionally stored (the backward's saved activations, the output)
+//   backward, hidden  acc = W_h^T dZ;        dZ <- acc * leaky'(saved activation of the layer below);  stored for dW = dZ^T X
+//   backward, input   acc = W_x^T dZ;        added to dL/dx0 in memory, the register state is kept
+// so the same code walks the network in both directions (the backward's matrices are the transposed blocks, packed the same
+// way); the weight gradients are library GEMMs over the stored dZ and activations (splatfields_amd/fused_mlp.py).
+//
+// Packed matrix with MT output tiles and KT input tiles (host side: splatfields_amd/fused_mlp.py):
+//   float index ((((c * MT + mt) * 2 + tl) * 64 + lane) * 4 + i)  =  A[16 mt + (lane & 15)][16 (2 c + tl) + 4 (lane >> 4) + i]
+// (zero beyond the matrix's true sizes), bias padded to 16 MT floats.
 #include "kernels.h"
 
 namespace sr {
@@ -23,21 +31,21 @@ namespace sr {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMlpMaxLayers = 12;
-struct MlpLayerK { const float* w; const float* b; int mt, mem_t, reg_t; };   // output tiles; input tiles from x0 / from the previous layer
-struct MlpK { int n_layers; MlpLayerK layer[kMlpMaxLayers]; };
+constexpr int kMlpMaxOps = SR_MLP_MAX_OPS;
+struct MlpK { int n_ops; SrMlpOp op[kMlpMaxOps]; };
 
 template <int HT>
-__global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_points, const float* __restrict__ x0, int x0_row,
-                                                        float* __restrict__ y, int out_features, float slope) {
-    __shared__ float4 s_w[2][HT * 2 * 64];   // two chunks of packed weights: [mt][tl][lane]
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mlp_chain(const MlpK net, int n_points, float slope) {
+    __shared__ float4 s_w[2][HT * 2 * 64];   // two chunks of a packed matrix: [mt][tl][lane]
     const int wave = wave_id(), lane = lane_id();
     const int k = lane >> 4, n = lane & 15;
     const int p0 = (blockIdx.x * 4 + wave) * 32;              // first point of this wavefront
     int prow[2];                                              // this lane's point of each of the two point tiles (clamped)
+    bool pvalid[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) prow[nt] = min(p0 + 16 * nt + n, n_points - 1);
+    for (int nt = 0; nt < 2; ++nt) { prow[nt] = min(p0 + 16 * nt + n, n_points - 1); pvalid[nt] = p0 + 16 * nt + n < n_points; }
 
     f32x4 prev[2][HT], acc[2][HT];
 #pragma unroll
@@ -46,11 +54,11 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
         for (int t = 0; t < HT; ++t) prev[nt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int buf = 0;
-    for (int l = 0; l < net.n_layers; ++l) {
-        const MlpLayerK L = net.layer[l];
-        const float4* w4 = reinterpret_cast<const float4*>(L.w);
-        const int chunk_f4 = L.mt * 128;                       // float4 per chunk: mt x 2 x 64
-        const int n_chunks = (L.mem_t + L.reg_t) / 2;
+    for (int l = 0; l < net.n_ops; ++l) {
+        const SrMlpOp L = net.op[l];
+        const float4* w4 = reinterpret_cast<const float4*>(L.w_packed);
+        const int chunk_f4 = L.out_tiles * 128;                // float4 per chunk: mt x 2 x 64
+        const int n_chunks = (L.mem_tiles + L.reg_tiles) / 2;
         auto stage = [&](int c, int into) {
             for (int j = (int)threadIdx.x; j < chunk_f4; j += kBlock) s_w[into][j] = w4[(size_t)c * chunk_f4 + j];
         };
@@ -58,14 +66,14 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (mt < L.mt) { const float4 t4 = reinterpret_cast<const float4*>(L.b)[4 * mt + k]; b4 = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
+            if (L.bias && mt < L.out_tiles) { const float4 t4 = reinterpret_cast<const float4*>(L.bias)[4 * mt + k]; b4 = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
             acc[0][mt] = b4; acc[1][mt] = b4;
         }
-        __syncthreads();          // everyone has left the previous layer's last chunk
+        __syncthreads();          // everyone has left the previous op's last chunk
         stage(0, buf);
         int c = 0;
-        // ---- input channels that come from memory (the network input; also the skip connection) ----
-        for (; c < L.mem_t / 2; ++c) {
+        // ---- input channels that come from memory (the network input / skip connection; the top gradient) ----
+        for (; c < L.mem_tiles / 2; ++c) {
             __syncthreads();      // chunk c has landed; the other buffer is free
             if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
 #pragma unroll
@@ -73,10 +81,10 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
                 const int t = 2 * c + tl;
                 float4 b4[2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(x0 + (size_t)prow[nt] * x0_row + 16 * t + 4 * k);
+                for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(L.src + (size_t)prow[nt] * L.src_row + 16 * t + 4 * k);
 #pragma unroll
                 for (int mt = 0; mt < HT; ++mt) {
-                    if (mt < L.mt) {
+                    if (mt < L.out_tiles) {
                         const float4 a4 = s_w[buf][(mt * 2 + tl) * 64 + lane];
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
@@ -90,10 +98,10 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
             }
             buf ^= 1;
         }
-        // ---- input channels that are the previous layer's accumulators (compile-time register indices) ----
+        // ---- input channels that are the register state (compile-time register indices) ----
 #pragma unroll
         for (int cr = 0; cr < HT / 2; ++cr) {
-            if (cr < L.reg_t / 2) {
+            if (cr < L.reg_tiles / 2) {
                 __syncthreads();
                 if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
 #pragma unroll
@@ -101,7 +109,7 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
                     const int t = 2 * cr + tl;
 #pragma unroll
                     for (int mt = 0; mt < HT; ++mt) {
-                        if (mt < L.mt) {
+                        if (mt < L.out_tiles) {
                             const float4 a4 = s_w[buf][(mt * 2 + tl) * 64 + lane];
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt) {
@@ -117,52 +125,251 @@ __global__ void __launch_bounds__(kBlock) k_mlp_forward(const MlpK net, int n_po
                 ++c;
             }
         }
-        // ---- activation (after EVERY layer, the last one included: time_utils.py:185-186); becomes the next layer's input ----
+        // ---- epilogue: channel 16 mt + 4 k + i of point (nt, n) ----
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < HT; ++mt)
+            for (int mt = 0; mt < HT; ++mt) {
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                if (mt < L.out_tiles) {
+                    r = acc[nt][mt];
+                    if (L.epilogue == SR_MLP_LEAKY) {            // activation of a forward layer (leaky ReLU, 0 <= slope < 1)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x = mt < L.mt ? acc[nt][mt][i] : 0.f;
-                    prev[nt][mt][i] = fmaxf(x, slope * x);   // leaky ReLU, 0 <= slope < 1
+                        for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], slope * r[i]);
+                    } else if (L.epilogue == SR_MLP_MASK) {      // backward: times leaky'(x), read off the saved activation's sign
+                        const float4 m4 = *reinterpret_cast<const float4*>(L.mask + (size_t)prow[nt] * L.mask_row + 16 * mt + 4 * k);
+                        r[0] *= m4.x > 0.f ? 1.0f : slope; r[1] *= m4.y > 0.f ? 1.0f : slope;
+                        r[2] *= m4.z > 0.f ? 1.0f : slope; r[3] *= m4.w > 0.f ? 1.0f : slope;
+                    }
+                    if (L.store && pvalid[nt]) {
+                        float* dst = L.store + (size_t)(p0 + 16 * nt + n) * L.store_row + 16 * mt + 4 * k;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (16 * mt + 4 * k + i < L.store_channels) dst[i] = L.store_accumulate ? dst[i] + r[i] : r[i];
+                    }
                 }
+                if (!L.keep_state) prev[nt][mt] = r;
+            }
     }
-    // ---- the last layer's activations leave: channel 16 mt + 4 k + i of point (nt, n) ----
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int p = p0 + 16 * nt + n;
-        if (p < n_points) {
-#pragma unroll
-            for (int mt = 0; mt < HT; ++mt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ch = 16 * mt + 4 * k + i;
-                    if (ch < out_features) y[(size_t)p * out_features + ch] = prev[nt][mt][i];
-                }
-        }
+}
+
+struct MlpPackK { SrMlpPackJob job[SR_MLP_MAX_PACK_JOBS]; };
+
+// One packed float per thread step: thread index = the destination index, decoded to (c, mt, tl, lane, i) -> (row, column).
+__global__ void __launch_bounds__(kBlock) k_mlp_pack(const MlpPackK jobs) {
+    const SrMlpPackJob J = jobs.job[blockIdx.y];
+    const int kt = (J.mem_pad + J.reg_width) / 16;
+    const int total = 16 * J.out_tiles * 16 * kt;
+    for (int d = blockIdx.x * kBlock + (int)threadIdx.x; d < total; d += gridDim.x * kBlock) {
+        const int i = d & 3, lane = (d >> 2) & 63, tl = (d >> 8) & 1;
+        const int rest = d >> 9;                       // c * MT + mt
+        const int mt = rest % J.out_tiles, c = rest / J.out_tiles;
+        const int r = 16 * mt + (lane & 15);
+        const int cp = 16 * (2 * c + tl) + 4 * (lane >> 4) + i;
+        int col = -1;
+        if (cp < J.mem_pad) { if (cp < J.n_mem) col = J.mem_col0 + cp; }
+        else if (cp - J.mem_pad < J.n_reg) col = J.reg_col0 + cp - J.mem_pad;
+        float v = 0.0f;
+        if (r < J.n_rows && col >= 0) v = J.transposed ? J.w[(size_t)col * J.ld + J.row0 + r] : J.w[(size_t)(J.row0 + r) * J.ld + col];
+        J.dst[d] = v;
     }
+    if (J.bias_dst && blockIdx.x == 0)
+        for (int j = (int)threadIdx.x; j < 16 * J.out_tiles; j += kBlock) J.bias_dst[j] = j < J.n_bias ? J.bias_src[j] : 0.0f;
+}
+
+// ---- weight gradients: dW[m][c] = sum over points of dZ[p][m] X[p][c], db[m] = sum over points of dZ[p][m] -------------------------
+// The contraction runs over the POINTS (10^5), the result is tiny (128 x 222): library GEMMs serialise it (0.27 ms for one
+// 128 x 128 x 100k product on MI355X, 12 TFLOP/s; eight of them were 2.7 of the 3.9 ms of a GeneralMLP training step).  Here
+// the points are cut into slabs, one workgroup column per slab; a wavefront owns one 64 x 64 block of one layer's dW and walks its
+// slab four points per MFMA step.  Operands come straight from memory with NO transpose: lane (kk, n) loads float4 = channels
+// 4n..4n+3 of point s + kk from dZ and from X (256 contiguous bytes per point row), and register i of the dZ load with
+// register j of the X load feed tile (i, j), whose MFMA row m' stands for dZ channel 4 m' + i and column n' for X channel
+// 4 n' + j: 2 loads per 16 MFMAs.  Partial blocks go to a workspace and a second kernel adds them over the slabs in a fixed
+// order (deterministic, no float atomics).
+constexpr int kGradMaxSlabs = 256;
+struct GradTask { unsigned char job, bm, bk, bias; };
+struct MlpGradK {
+    int n_tasks, n_points, slab, n_slabs;
+    float* part;          // [task][slab][64][64]
+    float* bias_part;     // [task][slab][64]
+    SrMlpGradJob job[SR_MLP_MAX_GRAD_JOBS];
+    GradTask task[SR_MLP_MAX_GRAD_TASKS];
+};
+
+__global__ void __launch_bounds__(kBlock) k_mlp_weight_grad(const MlpGradK P) {
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave_id());   // wave-uniform: the job's fields stay in SGPRs
+    if (t >= P.n_tasks) return;                       // no barriers below
+    const GradTask T = P.task[t];
+    const SrMlpGradJob J = P.job[T.job];
+    const int lane = lane_id(), kk = lane >> 4, n = lane & 15;
+    const int s_begin = blockIdx.x * P.slab, s_end = min(P.n_points, s_begin + P.slab);
+    // Buffer loads: a byte offset beyond the buffer reads as 0, so rows past the slab's end and channel groups past the row
+    // width need no branch (the compiler turns "load, then zero if invalid" back into a branch around the load, which
+    // serialises the four steps kept in flight below).
+    const bool zok = 64 * T.bm + 4 * n + 3 < J.dz_row, xok = 64 * T.bk + 4 * n + 3 < J.x_row;
+    const unsigned zcol = 4u * (64 * T.bm + 4 * n), xcol = 4u * (64 * T.bk + 4 * n);
+    const unsigned zbytes = 4u * (unsigned)J.dz_row, xbytes = 4u * (unsigned)J.x_row;
+    const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.dz), 0, (int)(zbytes * (unsigned)P.n_points), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.x), 0, (int)(xbytes * (unsigned)P.n_points), 0x00020000);
+    auto ldz = [&](int p) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(zsrc, (zok && p < s_end) ? (unsigned)p * zbytes + zcol : 0xfffffff0u, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto ldx = [&](int p) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xsrc, (xok && p < s_end) ? (unsigned)p * xbytes + xcol : 0xfffffff0u, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SR_GRAD_ROW(i, ai, b)                                                                \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.x, acc[i][0], 0, 0, 0);        \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.y, acc[i][1], 0, 0, 0);        \
+        acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.z, acc[i][2], 0, 0, 0);        \
+        acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b.w, acc[i][3], 0, 0, 0);
+#define SR_GRAD_STEP(a, b, next)                                                              \
+        colsum.x += a.x; colsum.y += a.y; colsum.z += a.z; colsum.w += a.w;                    \
+        SR_GRAD_ROW(0, a.x, b) SR_GRAD_ROW(1, a.y, b) SR_GRAD_ROW(2, a.z, b) SR_GRAD_ROW(3, a.w, b) \
+        a = ldz(next); b = ldx(next);
+    float4 a0 = ldz(s_begin + kk), b0 = ldx(s_begin + kk);
+    float4 a1 = ldz(s_begin + 4 + kk), b1 = ldx(s_begin + 4 + kk);
+    float4 a2 = ldz(s_begin + 8 + kk), b2 = ldx(s_begin + 8 + kk);
+    float4 a3 = ldz(s_begin + 12 + kk), b3 = ldx(s_begin + 12 + kk);
+    for (int s = s_begin; s < s_end; s += 16) {       // four steps of four points; steps past the slab's end add zeros
+        SR_GRAD_STEP(a0, b0, s + 16 + kk)
+        SR_GRAD_STEP(a1, b1, s + 20 + kk)
+        SR_GRAD_STEP(a2, b2, s + 24 + kk)
+        SR_GRAD_STEP(a3, b3, s + 28 + kk)
+    }
+#undef SR_GRAD_STEP
+#undef SR_GRAD_ROW
+    // lane (kk, n), tile (i, j), register r  =  block row 16 kk + 4 r + i, block column 4 n + j
+    float* out = P.part + ((size_t)t * P.n_slabs + blockIdx.x) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float4*>(out + (16 * kk + 4 * r + i) * 64 + 4 * n) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+    if (T.bias) {                                     // column sums of dZ: add the four point phases kk
+        colsum.x += __shfl_xor(colsum.x, 16); colsum.y += __shfl_xor(colsum.y, 16); colsum.z += __shfl_xor(colsum.z, 16); colsum.w += __shfl_xor(colsum.w, 16);
+        colsum.x += __shfl_xor(colsum.x, 32); colsum.y += __shfl_xor(colsum.y, 32); colsum.z += __shfl_xor(colsum.z, 32); colsum.w += __shfl_xor(colsum.w, 32);
+        if (kk == 0) *reinterpret_cast<float4*>(P.bias_part + ((size_t)t * P.n_slabs + blockIdx.x) * 64 + 4 * n) = colsum;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mlp_weight_grad_reduce(const MlpGradK P) {
+    const int t = blockIdx.y;
+    const GradTask T = P.task[t];
+    const SrMlpGradJob J = P.job[T.job];
+    const int e = blockIdx.x * kBlock + (int)threadIdx.x;
+    if (e < 4096) {
+        const int m = 64 * T.bm + (e >> 6), c = 64 * T.bk + (e & 63);
+        if (m >= J.m || c >= J.k) return;
+        const float* src = P.part + (size_t)t * P.n_slabs * 4096 + e;
+        float sum = 0.0f;
+        for (int s = 0; s < P.n_slabs; ++s) sum += src[(size_t)s * 4096];
+        J.dw[(size_t)m * J.dw_row + J.dw_col0 + c] = sum;
+    } else if (e < 4096 + 64 && T.bias) {
+        const int m = 64 * T.bm + (e - 4096);
+        if (m >= J.m) return;
+        const float* src = P.bias_part + (size_t)t * P.n_slabs * 64 + (e - 4096);
+        float sum = 0.0f;
+        for (int s = 0; s < P.n_slabs; ++s) sum += src[(size_t)s * 64];
+        J.db[m] = sum;
+    }
+}
+
+// Fills the task table; returns the number of tasks or -1.
+static int grad_tasks(int n_points, int n_jobs, const SrMlpGradJob* jobs, MlpGradK* k) {
+    if (n_jobs < 1 || n_jobs > SR_MLP_MAX_GRAD_JOBS) return -1;
+    int nt = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const SrMlpGradJob& s = jobs[j];
+        if (!s.dz || !s.x || !s.dw || s.m < 1 || s.k < 1 || s.m > s.dz_row || s.k > s.x_row || (s.dz_row & 3) || (s.x_row & 3) ||
+            (reinterpret_cast<uintptr_t>(s.dz) & 15u) || (reinterpret_cast<uintptr_t>(s.x) & 15u) || s.dw_col0 < 0 || s.dw_col0 + s.k > s.dw_row ||
+            s.m > 64 * 255 || s.k > 64 * 255) return -1;
+        if (n_points > 0 && ((size_t)n_points * s.dz_row * 4 >= (1ull << 31) || (size_t)n_points * s.x_row * 4 >= (1ull << 31))) return -1;   // 32-bit buffer offsets
+        if (k) k->job[j] = s;
+        for (int bm = 0; bm < (s.m + 63) / 64; ++bm)
+            for (int bk = 0; bk < (s.k + 63) / 64; ++bk) {
+                if (nt >= SR_MLP_MAX_GRAD_TASKS) return -1;
+                if (k) k->task[nt] = GradTask{(unsigned char)j, (unsigned char)bm, (unsigned char)bk, (unsigned char)(s.db && bk == 0)};
+                ++nt;
+            }
+    }
+    return nt;
+}
+
+static void grad_slabs(int n_points, int* slab, int* n_slabs) {
+    const int per = (n_points + kGradMaxSlabs - 1) / kGradMaxSlabs;
+    *slab = max(64, (per + 3) / 4 * 4);
+    *n_slabs = max(1, (n_points + *slab - 1) / *slab);
 }
 
 }  // namespace
 
-int launch_mlp_forward(int n_points, int hidden_tiles, int n_layers, const SrMlpLayer* layers, const float* x0, int x0_row,
-                       float* y, int out_features, float slope, hipStream_t st) {
-    if (n_layers < 1 || n_layers > kMlpMaxLayers) return 1;
-    MlpK net;
-    net.n_layers = n_layers;
-    for (int l = 0; l < n_layers; ++l) {
-        const SrMlpLayer& s = layers[l];
-        if (s.out_tiles < 1 || s.out_tiles > hidden_tiles || s.mem_tiles < 0 || s.reg_tiles < 0 || s.reg_tiles > hidden_tiles ||
-            (s.mem_tiles & 1) || (s.reg_tiles & 1) || s.mem_tiles + s.reg_tiles < 2 || !s.w_packed || !s.bias) return 1;
-        if (s.mem_tiles * 16 > x0_row) return 1;
-        net.layer[l] = MlpLayerK{s.w_packed, s.bias, s.out_tiles, s.mem_tiles, s.reg_tiles};
+size_t mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob* jobs) {
+    const int nt = grad_tasks(n_points, n_jobs, jobs, nullptr);
+    if (nt < 0 || n_points < 0) return 0;
+    int slab, n_slabs;
+    grad_slabs(n_points, &slab, &n_slabs);
+    return (size_t)nt * n_slabs * (4096 + 64) * sizeof(float);
+}
+
+int launch_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    MlpGradK k;
+    const int nt = grad_tasks(n_points, n_jobs, jobs, &k);
+    if (nt < 0 || n_points < 1) return 1;
+    grad_slabs(n_points, &k.slab, &k.n_slabs);
+    if (!workspace || workspace_bytes < (size_t)nt * k.n_slabs * (4096 + 64) * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15u)) return 1;
+    k.n_tasks = nt; k.n_points = n_points;
+    k.part = static_cast<float*>(workspace);
+    k.bias_part = k.part + (size_t)nt * k.n_slabs * 4096;
+    hipLaunchKernelGGL(k_mlp_weight_grad, dim3(k.n_slabs, (nt + 3) / 4), dim3(kBlock), 0, st, k);
+    hipLaunchKernelGGL(k_mlp_weight_grad_reduce, dim3((4096 + 64 + kBlock - 1) / kBlock, nt), dim3(kBlock), 0, st, k);
+    return 0;
+}
+
+int launch_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, hipStream_t st) {
+    if (n_jobs < 0 || n_jobs > SR_MLP_MAX_PACK_JOBS) return 1;
+    if (n_jobs == 0) return 0;
+    MlpPackK k;
+    int most = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const SrMlpPackJob& s = jobs[j];
+        if (!s.w || !s.dst || s.out_tiles < 1 || s.ld < 1 || s.row0 < 0 || s.n_rows < 0 || s.n_rows > 16 * s.out_tiles ||
+            s.n_mem < 0 || s.n_mem > s.mem_pad || s.n_reg < 0 || s.n_reg > s.reg_width || (s.mem_pad & 31) || (s.reg_width & 15) ||
+            (((s.mem_pad + s.reg_width) / 16) & 1) || s.mem_pad + s.reg_width < 32 || (reinterpret_cast<uintptr_t>(s.dst) & 15u) ||
+            (s.bias_dst && (!s.bias_src || s.n_bias < 0 || s.n_bias > 16 * s.out_tiles))) return 1;
+        k.job[j] = s;
+        most = max(most, 16 * s.out_tiles * (s.mem_pad + s.reg_width));
     }
-    if (out_features < 1 || out_features > 16 * layers[n_layers - 1].out_tiles) return 1;
+    const int bx = min(64, (most + kBlock * 4 - 1) / (kBlock * 4));
+    hipLaunchKernelGGL(k_mlp_pack, dim3(bx, n_jobs), dim3(kBlock), 0, st, k);
+    return 0;
+}
+
+int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float slope, hipStream_t st) {
+    if (n_ops < 1 || n_ops > kMlpMaxOps) return 1;
+    MlpK net;
+    net.n_ops = n_ops;
+    for (int l = 0; l < n_ops; ++l) {
+        const SrMlpOp& s = ops[l];
+        if (s.out_tiles < 1 || s.out_tiles > hidden_tiles || s.mem_tiles < 0 || s.reg_tiles < 0 || s.reg_tiles > hidden_tiles ||
+            (s.mem_tiles & 1) || (s.reg_tiles & 1) || s.mem_tiles + s.reg_tiles < 2 || !s.w_packed) return 1;
+        if (s.mem_tiles > 0 && (!s.src || s.mem_tiles * 16 > s.src_row || (s.src_row & 3) || (reinterpret_cast<uintptr_t>(s.src) & 15u))) return 1;
+        if (s.epilogue != SR_MLP_NONE && s.epilogue != SR_MLP_LEAKY && s.epilogue != SR_MLP_MASK) return 1;
+        if (s.epilogue == SR_MLP_MASK && (!s.mask || s.out_tiles * 16 > s.mask_row || (s.mask_row & 3) || (reinterpret_cast<uintptr_t>(s.mask) & 15u))) return 1;
+        if (s.store && (s.store_channels < 1 || s.store_channels > s.store_row || s.store_channels > 16 * s.out_tiles)) return 1;
+        net.op[l] = s;
+    }
     if (n_points <= 0) return 0;
     const int blocks = (n_points + 127) / 128;
-    if (hidden_tiles == 8) hipLaunchKernelGGL((k_mlp_forward<8>), dim3(blocks), dim3(kBlock), 0, st, net, n_points, x0, x0_row, y, out_features, slope);
-    else if (hidden_tiles == 4) hipLaunchKernelGGL((k_mlp_forward<4>), dim3(blocks), dim3(kBlock), 0, st, net, n_points, x0, x0_row, y, out_features, slope);
+    if (hidden_tiles == 8) hipLaunchKernelGGL((k_mlp_chain<8>), dim3(blocks), dim3(kBlock), 0, st, net, n_points, slope);
+    else if (hidden_tiles == 4) hipLaunchKernelGGL((k_mlp_chain<4>), dim3(blocks), dim3(kBlock), 0, st, net, n_points, slope);
     else return 1;
     return 0;
 }

@@ -1,15 +1,19 @@
-"""Fused forward of the SplatFields deform network's MLPs (include/splatraster.h: sr_mlp_forward; csrc/mlp.hip).
+"""Fused MLPs of the SplatFields deform network, forward and backward (include/splatraster.h: sr_mlp_chain, sr_mlp_pack;
+csrc/mlp.hip).
 
-`FusedGeneralMLP` evaluates one `GeneralMLP` of reference utils/time_utils.py:123-191 -- `h = act(layer_i(h))` for every
-layer, `h = cat([h_in, h])` after the layers listed in `skips` -- for all points in one kernel (activations in registers,
-exact fp32 MFMA).  It takes the layers' *effective* weights: for ResField layers (reference utils/resfields.py:378-405) the
-caller composes `W + delta(frame)` first.  Forward only (rendering / evaluation of trained 4-D models, reference render.py);
-the backward is the next step of this row.  No CPU path.
+`fused_general_mlp` evaluates one `GeneralMLP` of reference utils/time_utils.py:123-191 -- `h = act(layer_i(h))` for every
+layer, `h = cat([h_in, h])` after the layers listed in `skips`, act = leaky ReLU -- for all points in one kernel
+(activations in registers, exact fp32 MFMA), and is differentiable: the backward runs the activation-gradient chain
+dZ_{l-1} = (W_l^T dZ_l) * act'(.) and dL/dh_in in one more kernel of the same shape, and takes the weight gradients
+dW_l = dZ_l^T [h_in | h_{l-1}], db_l = sum dZ_l as library GEMMs / reductions over the dZ the kernel stored.  It takes the
+layers' *effective* weights as ordinary autograd tensors: for ResField layers (reference utils/resfields.py:378-405) the
+caller composes `W + delta(frame)` first and autograd carries dW on to W and the delta factors.  `FusedGeneralMLP` is the
+module-style wrapper.  No CPU path.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -18,9 +22,10 @@ from . import _lib
 
 
 def pack_layer_weight(W: torch.Tensor, n_mem: int, mem_pad: int, reg_width: int, out_tiles: int) -> torch.Tensor:
-    """W [M, n_mem + n_reg] (the reference's column order: network input first, hidden state after it) -> the packed K order
-    of csrc/mlp.hip: float ((((c MT + mt) 2 + tl) 64 + 16 k + m) 4 + i) = W'[16 mt + m][16 (2 c + tl) + 4 k + i], where W' is W
-    with the input block zero-padded to `mem_pad` columns, the hidden block to `reg_width`, and the rows to 16 `out_tiles`."""
+    """PyTorch statement of the packing (the device packer sr_mlp_pack is tested against it).  W [M, n_mem + n_reg] (the
+    reference's column order: network input first, hidden state after it) -> the packed K order of csrc/mlp.hip:
+    float ((((c MT + mt) 2 + tl) 64 + 16 k + m) 4 + i) = W'[16 mt + m][16 (2 c + tl) + 4 k + i], where W' is W with the input
+    block zero-padded to `mem_pad` columns, the hidden block to `reg_width`, and the rows to 16 `out_tiles`."""
     M, K = W.shape
     n_reg = K - n_mem
     Wp = W.new_zeros(16 * out_tiles, mem_pad + reg_width)
@@ -33,64 +38,228 @@ def pack_layer_weight(W: torch.Tensor, n_mem: int, mem_pad: int, reg_width: int,
     return v.permute(2, 0, 3, 4, 1, 5).contiguous().reshape(-1)   # (c, mt, tl, k, m, i)
 
 
+class _Shape:
+    """Static description of one GeneralMLP: which layers read the network input, tile counts, validity."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], d_in: int, skips: Sequence[int]):
+        self.n_layers = len(weights)
+        if self.n_layers < 2:
+            raise ValueError("a fused MLP has at least two layers")
+        self.d_in = int(d_in)
+        self.hidden = int(weights[0].shape[0])
+        if self.hidden not in (64, 128):
+            raise ValueError("fused MLPs support hidden widths 64 and 128")
+        self.ht = self.hidden // 16
+        self.skips = {int(s) for s in skips if 0 <= int(s) < self.n_layers - 1}
+        self.out_features = int(weights[-1].shape[0])
+        if self.out_features > self.hidden:
+            raise ValueError("the output may not be wider than the hidden layers")
+        self.out_tiles_last = (self.out_features + 15) // 16
+        self.out_pad = (self.out_features + 31) // 32 * 32      # the top gradient is a memory input: two tiles per chunk
+        self.mem_pad = (self.d_in + 31) // 32 * 32
+        self.reads_input = [j == 0 or (j - 1) in self.skips for j in range(self.n_layers)]
+        for j, W in enumerate(weights):
+            want = self.d_in if j == 0 else self.hidden + (self.d_in if self.reads_input[j] else 0)
+            rows = self.hidden if j < self.n_layers - 1 else self.out_features
+            if tuple(W.shape) != (rows, want):
+                raise ValueError(f"layer {j}: expected weight [{rows}, {want}], got {tuple(W.shape)}")
+        # input-gradient ops write <= ht tiles each
+        self.input_groups = [(g, min(self.ht, self.mem_pad // 16 - g)) for g in range(0, self.mem_pad // 16, self.ht)
+                             if self.d_in - 16 * g > 0]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class _Builder:
+    """Collects pack jobs (one device launch) and the op list that uses their outputs."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs: List[dict] = []
+        self.sizes: List[Tuple[int, int]] = []
+        self.ops: List[dict] = []
+
+    def add(self, job: dict, op: dict, with_bias: bool):
+        floats = 16 * job["out_tiles"] * (job["mem_pad"] + job["reg_width"])
+        self.jobs.append(job)
+        self.sizes.append((floats, 16 * job["out_tiles"] if with_bias else 0))
+        self.ops.append(op)
+
+    def run(self, lib, n_points: int, ht: int, slope: float, stream) -> torch.Tensor:
+        if len(self.jobs) > _lib.MLP_MAX_PACK_JOBS or len(self.ops) > _lib.MLP_MAX_OPS:
+            raise ValueError("network too deep for one fused chain")
+        total = sum(a + b for a, b in self.sizes)
+        buf = torch.empty(total, dtype=torch.float32, device=self.device)
+        base, at = buf.data_ptr(), 0
+        jobs = (_lib.SrMlpPackJob * len(self.jobs))()
+        ops = (_lib.SrMlpOp * len(self.ops))()
+        for j, (job, op, (wf, bf)) in enumerate(zip(self.jobs, self.ops, self.sizes)):
+            w_at = base + 4 * at
+            b_at = base + 4 * (at + wf) if bf else None
+            at += wf + bf
+            jobs[j] = _lib.SrMlpPackJob(w=job["w"], bias_src=job.get("bias"), dst=w_at, bias_dst=b_at, ld=job["ld"],
+                                        transposed=job["transposed"], row0=job["row0"], n_rows=job["n_rows"], n_mem=job["n_mem"],
+                                        mem_pad=job["mem_pad"], mem_col0=0, n_reg=job["n_reg"], reg_width=job["reg_width"],
+                                        reg_col0=job["reg_col0"], out_tiles=job["out_tiles"], n_bias=job.get("n_bias", 0))
+            ops[j] = _lib.SrMlpOp(w_packed=w_at, bias=b_at, src=op.get("src"), mask=op.get("mask"), store=op.get("store"),
+                                  out_tiles=job["out_tiles"], mem_tiles=job["mem_pad"] // 16, reg_tiles=job["reg_width"] // 16,
+                                  src_row=op.get("src_row", 0), epilogue=op["epilogue"], mask_row=op.get("mask_row", 0),
+                                  store_row=op.get("store_row", 0), store_channels=op.get("store_channels", 0),
+                                  store_accumulate=op.get("store_accumulate", 0), keep_state=op.get("keep_state", 0))
+        _lib.check(lib.sr_mlp_pack(len(self.jobs), jobs, C.c_void_p(stream)))
+        _lib.check(lib.sr_mlp_chain(n_points, ht, len(self.ops), ops, slope, C.c_void_p(stream)))
+        return buf      # alive until the caller drops it; the stream orders its reuse
+
+
+def _forward(shape: _Shape, x0: torch.Tensor, weights, biases, slope: float, save: bool):
+    """x0 [N, mem_pad] -> (y [N, out], acts [L-1, N, hidden] or None)."""
+    lib = _lib.load()
+    dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
+    y = torch.empty(n, shape.out_features, dtype=torch.float32, device=dev)
+    acts = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev) if save else None
+    b = _Builder(dev)
+    for j, (W, bias) in enumerate(zip(weights, biases)):
+        last = j == L - 1
+        n_mem = shape.d_in if shape.reads_input[j] else 0
+        job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=0, row0=0, n_rows=W.shape[0], n_mem=n_mem,
+                   mem_pad=shape.mem_pad if n_mem else 0, n_reg=W.shape[1] - n_mem, reg_width=0 if j == 0 else H, reg_col0=n_mem,
+                   out_tiles=shape.out_tiles_last if last else shape.ht, bias=bias.data_ptr(), n_bias=bias.shape[0])
+        op = dict(epilogue=_lib.MLP_LEAKY, src=x0.data_ptr() if n_mem else None, src_row=shape.mem_pad)
+        if last:
+            op.update(store=y.data_ptr(), store_row=shape.out_features, store_channels=shape.out_features)
+        elif save:
+            op.update(store=acts[j].data_ptr(), store_row=H, store_channels=H)
+        b.add(job, op, with_bias=True)
+    with torch.cuda.device(dev):
+        b.run(lib, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
+    return y, acts
+
+
+def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input: bool):
+    """-> (dL/dx0 [N, mem_pad] or None, G [N, out_pad] = dZ of the last layer (zero-padded), dz [L-1, N, hidden] = dZ of the others)."""
+    lib = _lib.load()
+    dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
+    gz = dY * torch.where(y > 0, 1.0, slope)
+    G = F.pad(gz, (0, shape.out_pad - shape.out_features)).contiguous()
+    dz = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev)
+    dx0 = torch.zeros(n, shape.mem_pad, dtype=torch.float32, device=dev) if need_input else None
+    b = _Builder(dev)
+    for j in range(L - 1, -1, -1):
+        W = weights[j]
+        top = j == L - 1
+        n_mem_w = shape.d_in if shape.reads_input[j] else 0        # columns of W_j that multiply the network input
+        # this layer's dZ is the op input: memory (G) for the top layer, the register state below it
+        cols = dict(n_mem=shape.out_features, mem_pad=shape.out_pad, n_reg=0, reg_width=0, reg_col0=0) if top else \
+            dict(n_mem=0, mem_pad=0, n_reg=H, reg_width=H, reg_col0=0)
+        src = dict(src=G.data_ptr(), src_row=shape.out_pad) if top else {}
+        if need_input and n_mem_w:
+            for g0, cnt in shape.input_groups:                      # dL/dx0 += W_j[:, input block]^T dZ_j, <= ht tiles at a time
+                rows = min(16 * cnt, shape.d_in - 16 * g0)
+                job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=1, row0=16 * g0, n_rows=rows, out_tiles=cnt, **cols)
+                op = dict(epilogue=_lib.MLP_NONE, keep_state=1, store=dx0.data_ptr() + 4 * 16 * g0, store_row=shape.mem_pad,
+                          store_channels=rows, store_accumulate=1, **src)
+                b.add(job, op, with_bias=False)
+        if j > 0:                                                   # dZ_{j-1} = (W_j[:, hidden block]^T dZ_j) * act'(h_{j-1})
+            job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=1, row0=n_mem_w, n_rows=H, out_tiles=shape.ht, **cols)
+            op = dict(epilogue=_lib.MLP_MASK, mask=acts[j - 1].data_ptr(), mask_row=H, store=dz[j - 1].data_ptr(), store_row=H,
+                      store_channels=H, **src)
+            b.add(job, op, with_bias=False)
+    with torch.cuda.device(dev):
+        b.run(lib, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
+    return dx0, G, dz
+
+
+def _weight_grads(shape: _Shape, x0, acts, G, dz, weights):
+    """dW_j = dZ_j^T [h_in | h_{j-1}], db_j = sum over points of dZ_j, all layers in one launch (sr_mlp_weight_grad)."""
+    lib = _lib.load()
+    dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
+    dWs = [torch.empty_like(W) for W in weights]
+    dbs = [torch.empty(W.shape[0], dtype=torch.float32, device=dev) for W in weights]
+    jobs = []
+    for j in range(L):
+        top = j == L - 1
+        dzj, dz_row, m = (G, shape.out_pad, shape.out_features) if top else (dz[j], H, H)
+        col0, first = 0, True
+        segments = []
+        if shape.reads_input[j]:
+            segments.append((x0, shape.mem_pad, shape.d_in))
+        if j > 0:
+            segments.append((acts[j - 1], H, H))
+        for x, x_row, k in segments:
+            jobs.append(_lib.SrMlpGradJob(dz=dzj.data_ptr(), x=x.data_ptr(), dw=dWs[j].data_ptr(), db=dbs[j].data_ptr() if first else None,
+                                          dz_row=dz_row, m=m, x_row=x_row, k=k, dw_row=dWs[j].shape[1], dw_col0=col0))
+            col0 += k
+            first = False
+    if len(jobs) > _lib.MLP_MAX_GRAD_JOBS:
+        raise ValueError("network too deep for one weight-gradient launch")
+    arr = (_lib.SrMlpGradJob * len(jobs))(*jobs)
+    ws_bytes = lib.sr_mlp_weight_grad_workspace(n, len(jobs), arr)
+    if ws_bytes == 0:
+        raise ValueError("unsupported weight-gradient job list: " + lib.sr_last_error().decode("utf-8", "replace"))
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_mlp_weight_grad(n, len(jobs), arr, C.c_void_p(ws.data_ptr()), ws_bytes,
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return dWs, dbs
+
+
+class _FusedMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h_in, shape: _Shape, slope: float, *params):
+        L = shape.n_layers
+        weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
+        biases = [p.detach().to(torch.float32).contiguous() for p in params[L:]]
+        x0 = F.pad(h_in.detach().to(torch.float32), (0, shape.mem_pad - shape.d_in)).contiguous()
+        need = any(ctx.needs_input_grad)
+        y, acts = _forward(shape, x0, weights, biases, slope, save=need)
+        if need:
+            ctx.shape, ctx.slope = shape, slope
+            ctx.save_for_backward(x0, acts, y, *weights)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        shape, slope = ctx.shape, ctx.slope
+        x0, acts, y, *weights = ctx.saved_tensors
+        L, d_in = shape.n_layers, shape.d_in
+        need_input = ctx.needs_input_grad[0]
+        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_input)
+        dWs, dbs = [None] * L, [None] * L
+        if any(ctx.needs_input_grad[3:]):
+            dWs, dbs = _weight_grads(shape, x0, acts, G, dz, weights)
+            dWs = [g if ctx.needs_input_grad[3 + j] else None for j, g in enumerate(dWs)]
+            dbs = [g if ctx.needs_input_grad[3 + L + j] else None for j, g in enumerate(dbs)]
+        return (dx0[:, :d_in] if need_input else None, None, None, *dWs, *dbs)
+
+
+def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], skips: Sequence[int] = (),
+                      negative_slope: float = 0.01, _shape: Optional[_Shape] = None) -> torch.Tensor:
+    """h_in [N, d_in] (positional encoding ++ features, as the reference builds it) -> [N, out_features]; differentiable with
+    respect to h_in, the weights and the biases.  weights[j]: [out_j, in_j] on the device, biases[j]: [out_j]; in_0 = d_in,
+    in_j = hidden (+ d_in when j - 1 is in `skips`); hidden width 64 or 128."""
+    _lib.load()
+    if not h_in.is_cuda:
+        raise RuntimeError("fused_general_mlp has no CPU path: tensors must be on a HIP ('cuda') device")
+    shape = _shape or _Shape(weights, h_in.shape[1] if h_in.dim() == 2 else -1, skips)
+    if h_in.dim() != 2 or h_in.shape[1] != shape.d_in:
+        raise ValueError(f"h_in must be [N, {shape.d_in}]")
+    if not (0.0 <= negative_slope < 1.0):
+        raise ValueError("negative_slope must be in [0, 1)")
+    return _FusedMLPFn.apply(h_in, shape, float(negative_slope), *weights, *biases)
+
+
 class FusedGeneralMLP:
-    """weights[j]: [out_j, in_j] float32 on the device, biases[j]: [out_j]; in_0 = d_in, in_j = hidden (+ d_in when j - 1 is in
-    `skips`), out_last = the network's output width.  Hidden width 64 or 128."""
+    """Module-style wrapper: holds the weight / bias tensors (leaf parameters or per-step composed ResField weights may be
+    swapped in through `weights` / `biases`) and the static shape."""
 
     def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], d_in: int, skips: Sequence[int] = (),
                  negative_slope: float = 0.01):
         self.weights, self.biases = list(weights), list(biases)
-        self.d_in, self.slope = int(d_in), float(negative_slope)
-        self.hidden = int(self.weights[0].shape[0])
-        if self.hidden not in (64, 128):
-            raise ValueError("FusedGeneralMLP supports hidden widths 64 and 128")
-        self.skips = {int(s) for s in skips if 0 <= int(s) < len(self.weights) - 1}
-        self.out_features = int(self.weights[-1].shape[0])
-        if self.out_features > self.hidden:
-            raise ValueError("the output may not be wider than the hidden layers")
-        self.mem_pad = (self.d_in + 31) // 32 * 32             # two 16-channel tiles per weight chunk
-        self._packed = None
-        self._versions = None
-        for j, W in enumerate(self.weights):
-            want = self.d_in if j == 0 else self.hidden + (self.d_in if (j - 1) in self.skips else 0)
-            if W.shape[1] != want:
-                raise ValueError(f"layer {j}: expected {want} input features, got {W.shape[1]}")
+        self.slope = float(negative_slope)
+        self.shape = _Shape(self.weights, d_in, skips)
+        self.d_in, self.hidden, self.out_features = self.shape.d_in, self.shape.hidden, self.shape.out_features
 
-    def _pack(self):
-        versions = tuple((w._version, b._version) for w, b in zip(self.weights, self.biases))
-        if self._packed is not None and versions == self._versions:
-            return self._packed
-        ht = self.hidden // 16
-        packed, descs = [], []
-        last = len(self.weights) - 1
-        for j, (W, b) in enumerate(zip(self.weights, self.biases)):
-            W = W.detach().to(torch.float32)
-            n_mem = self.d_in if (j == 0 or (j - 1) in self.skips) else 0
-            out_tiles = ht if j < last else (self.out_features + 15) // 16
-            wp = pack_layer_weight(W, n_mem, self.mem_pad if n_mem else 0, 0 if j == 0 else self.hidden, out_tiles)
-            bp = F.pad(b.detach().to(torch.float32), (0, 16 * out_tiles - b.shape[0])).contiguous()
-            packed.append((wp, bp))
-            descs.append((out_tiles, (self.mem_pad // 16) if n_mem else 0, 0 if j == 0 else ht))
-        arr = (_lib.SrMlpLayer * len(descs))()
-        for j, ((wp, bp), (ot, mt, rt)) in enumerate(zip(packed, descs)):
-            arr[j] = _lib.SrMlpLayer(wp.data_ptr(), bp.data_ptr(), ot, mt, rt)
-        self._packed, self._versions = (packed, arr), versions   # `packed` keeps the device buffers alive
-        return self._packed
-
-    @torch.no_grad()
     def __call__(self, h_in: torch.Tensor) -> torch.Tensor:
-        """h_in [N, d_in] (positional encoding ++ features, as the reference builds it) -> [N, out_features]."""
-        lib = _lib.load()
-        if not h_in.is_cuda:
-            raise RuntimeError("FusedGeneralMLP has no CPU path: tensors must be on a HIP ('cuda') device")
-        if h_in.dim() != 2 or h_in.shape[1] != self.d_in:
-            raise ValueError(f"h_in must be [N, {self.d_in}]")
-        dev, n = h_in.device, h_in.shape[0]
-        x0 = F.pad(h_in.detach().to(torch.float32), (0, self.mem_pad - self.d_in)).contiguous()
-        y = torch.empty(n, self.out_features, dtype=torch.float32, device=dev)
-        _, arr = self._pack()
-        with torch.cuda.device(dev):
-            _lib.check(lib.sr_mlp_forward(n, self.hidden // 16, len(self.weights), arr, C.c_void_p(x0.data_ptr()), self.mem_pad,
-                                          C.c_void_p(y.data_ptr()), self.out_features, self.slope,
-                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        return y
+        return fused_general_mlp(h_in, self.weights, self.biases, negative_slope=self.slope, _shape=self.shape)

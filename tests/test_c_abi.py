@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.sr_version() == 2
+    assert lib.sr_version() == 3
     g1, g2 = lib.sr_geom_bytes(1000, 64, 64), lib.sr_geom_bytes(2000, 64, 64)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.sr_binning_bytes(1000, 64, 64) >= 1000 * 28  # ent 8 + merge ping-pong 2 x 8 + sorted ids 4 bytes per instance
@@ -100,3 +100,7 @@ def test_header_constants_match_the_binding():
     assert (defs["SR_RAW_SCALES"], defs["SR_RAW_OPACITY"], defs["SR_RAW_ROTATIONS"], defs["SR_FORWARD_ONLY"]) == \
         (_lib.SR_RAW_SCALES, _lib.SR_RAW_OPACITY, _lib.SR_RAW_ROTATIONS, _lib.SR_FORWARD_ONLY)
     assert defs["SR_PROFILE_STAGES"] == _lib.PROFILE_STAGES
+    assert defs["SR_MLP_MAX_PACK_JOBS"] == _lib.MLP_MAX_PACK_JOBS
+    assert (defs["SR_MLP_MAX_GRAD_JOBS"], defs["SR_MLP_MAX_GRAD_TASKS"]) == (_lib.MLP_MAX_GRAD_JOBS, _lib.MLP_MAX_GRAD_TASKS)
+    assert (defs["SR_MLP_MAX_OPS"], defs["SR_MLP_NONE"], defs["SR_MLP_LEAKY"], defs["SR_MLP_MASK"]) == \
+        (_lib.MLP_MAX_OPS, _lib.MLP_NONE, _lib.MLP_LEAKY, _lib.MLP_MASK)

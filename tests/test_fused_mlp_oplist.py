@@ -1,0 +1,121 @@
+"""Host logic of the fused MLP (splatfields_amd/fused_mlp.py) without a GPU: the pack jobs and op lists it hands to
+sr_mlp_pack / sr_mlp_chain are interpreted here with plain PyTorch on CPU tensors (an op = one matrix applied to
+[memory channels | running state] + epilogue, include/splatraster.h), and the forward, dL/dh_in and the dZ of every layer
+they produce are compared with float64 autograd of the reference's GeneralMLP formula (utils/time_utils.py:178-191).  The
+kernels themselves are covered by tests/test_gpu_fused_mlp.py."""
+import contextlib
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def view(ptr, rows, row, cols):
+    n = (rows - 1) * row + cols
+    arr = (ctypes.c_float * n).from_address(ptr)
+    t = torch.frombuffer(arr, dtype=torch.float32)
+    return torch.as_strided(t, (rows, cols), (row, 1))
+
+def job_matrix(job):
+    K = job["n_mem"] + job["n_reg"]
+    ld = job["ld"]
+    R = 16 * job["out_tiles"]
+    A = torch.zeros(R, job["mem_pad"] + job["reg_width"])
+    nr = job["n_rows"]
+    def col(c): return c
+    if job["transposed"]:
+        # element = W[col][row0+r]
+        ncols_src = max(job["n_mem"], job["reg_col0"] + job["n_reg"])
+        W = view(job["w"], ncols_src, ld, job["row0"] + nr)
+        if job["n_mem"]: A[:nr, :job["n_mem"]] = W[:job["n_mem"], job["row0"]:job["row0"]+nr].t()
+        if job["n_reg"]: A[:nr, job["mem_pad"]:job["mem_pad"]+job["n_reg"]] = W[job["reg_col0"]:job["reg_col0"]+job["n_reg"], job["row0"]:job["row0"]+nr].t()
+    else:
+        W = view(job["w"], job["row0"] + nr, ld, job["reg_col0"] + job["n_reg"] if job["n_reg"] else job["n_mem"])
+        if job["n_mem"]: A[:nr, :job["n_mem"]] = W[job["row0"]:job["row0"]+nr, :job["n_mem"]]
+        if job["n_reg"]: A[:nr, job["mem_pad"]:job["mem_pad"]+job["n_reg"]] = W[job["row0"]:job["row0"]+nr, job["reg_col0"]:job["reg_col0"]+job["n_reg"]]
+    return A
+
+def interpret(self, lib, n, ht, slope, stream):
+    state = torch.zeros(n, 16 * ht)
+    for job, op in zip(self.jobs, self.ops):
+        A = job_matrix(job)
+        mem_t, reg_t = job["mem_pad"], job["reg_width"]
+        parts = []
+        if mem_t: parts.append(view(op["src"], n, op["src_row"], mem_t))
+        if reg_t: parts.append(state[:, :reg_t])
+        X = torch.cat(parts, 1)
+        acc = X @ A.t()
+        if job.get("bias"):
+            b = view(job["bias"], 1, job["n_bias"], job["n_bias"])[0]
+            acc[:, :job["n_bias"]] += b
+        ep = op["epilogue"]
+        if ep == 1: acc = torch.maximum(acc, slope * acc)
+        elif ep == 2:
+            m = view(op["mask"], n, op["mask_row"], acc.shape[1])
+            acc = acc * torch.where(m > 0, 1.0, slope)
+        if op.get("store"):
+            dst = view(op["store"], n, op["store_row"], op["store_channels"])
+            if op.get("store_accumulate"): dst += acc[:, :op["store_channels"]]
+            else: dst.copy_(acc[:, :op["store_channels"]])
+        if not op.get("keep_state"):
+            state = torch.zeros(n, 16 * ht); state[:, :acc.shape[1]] = acc
+
+
+def reference(h_in, ws, bs, skips, slope):
+    h = h_in
+    for i, (W, b) in enumerate(zip(ws, bs)):
+        h = F.leaky_relu(F.linear(h, W, b), slope)
+        if i in skips and i != len(ws) - 1:
+            h = torch.cat([h_in, h], -1)
+    return h
+
+
+@pytest.mark.parametrize("d_in,H,nh,skips,out", [(94, 128, 6, [3], 3), (82, 64, 4, [2], 3), (130, 64, 2, [0, 1], 16),
+                                                  (94, 128, 6, [3, 6], 128), (33, 128, 1, [], 5)])
+def test_op_lists_compute_the_network_and_its_gradients(monkeypatch, d_in, H, nh, skips, out):
+    from splatfields_amd import fused_mlp as fm, _lib
+
+    class _Stream:
+        cuda_stream = 0
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
+    monkeypatch.setattr(fm._Builder, "run", interpret)
+    g = torch.Generator().manual_seed(1)
+    L = nh + 2
+    dims_in = [d_in] + [H + (d_in if (j - 1) in skips else 0) for j in range(1, L)]
+    dims_out = [H] * (L - 1) + [out]
+    ws = [torch.randn(o, i, generator=g) / i ** 0.5 for i, o in zip(dims_in, dims_out)]
+    bs = [0.1 * torch.randn(o, generator=g) for o in dims_out]
+    n = 37
+    h_in, dY = torch.randn(n, d_in, generator=g), torch.randn(n, out, generator=g)
+    shape = fm._Shape(ws, d_in, skips)
+    x0 = F.pad(h_in, (0, shape.mem_pad - d_in)).contiguous()
+    y, acts = fm._forward(shape, x0, ws, bs, 0.05, True)
+    dx0, G, dz = fm._backward(shape, x0, acts, y, dY, ws, 0.05, True)
+    hr = h_in.double().requires_grad_()
+    wr, br = [w.double().requires_grad_() for w in ws], [b.double().requires_grad_() for b in bs]
+    yr = reference(hr, wr, br, set(skips), 0.05)
+    yr.backward(dY.double())
+    assert (y - yr).abs().max().item() <= 1e-5
+    assert (dx0[:, :d_in] - hr.grad).abs().max().item() <= 1e-5 and (dx0[:, d_in:] == 0).all()
+    for j in range(L):                                    # the contraction sr_mlp_weight_grad performs on these buffers
+        dZ = G[:, :out] if j == L - 1 else dz[j]
+        segments = ([x0[:, :d_in]] if shape.reads_input[j] else []) + ([acts[j - 1]] if j > 0 else [])
+        assert (dZ.t() @ torch.cat(segments, 1) - wr[j].grad).abs().max().item() <= 5e-5
+        assert (dZ.sum(0) - br[j].grad).abs().max().item() <= 5e-5
+    assert (G[:, out:] == 0).all()
+
+
+def test_shape_validation():
+    from splatfields_amd.fused_mlp import _Shape
+    w = [torch.zeros(128, 94), torch.zeros(128, 128), torch.zeros(3, 128)]
+    s = _Shape(w, 94, [5])                                 # a skip index past the hidden layers is ignored, as in the reference
+    assert s.reads_input == [True, False, False] and s.mem_pad == 96 and s.out_pad == 32 and s.input_groups == [(0, 6)]
+    with pytest.raises(ValueError):
+        _Shape([torch.zeros(100, 94), torch.zeros(3, 100)], 94, [])          # hidden width
+    with pytest.raises(ValueError):
+        _Shape(w, 94, [0])                                                   # layer 1 would need 94 + 128 inputs
+    with pytest.raises(ValueError):
+        _Shape(w[:1], 94, [])

@@ -1,5 +1,6 @@
-"""Fused MLP forward (splatfields_amd/fused_mlp.py -> sr_mlp_forward) against a PyTorch restatement of the reference's
-`GeneralMLP.forward` (utils/time_utils.py:178-191): fp32, <= 2e-5 relative to the output's magnitude."""
+"""Fused MLP (splatfields_amd/fused_mlp.py -> sr_mlp_pack / sr_mlp_chain) against a PyTorch restatement of the reference's
+`GeneralMLP.forward` (utils/time_utils.py:178-191): forward fp32 <= 2e-5 relative to the output's magnitude; gradients of
+h_in, every weight and bias against float64 autograd of the same formula, <= 1e-4 of each tensor's largest entry."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -75,3 +76,185 @@ def test_fused_forward_timing_vs_pytorch(hip_device):
         t_torch = timed(lambda: general_mlp_reference(h_in, weights, biases, {3}, 0.01))
     print(f"\nfused MLP forward, 100k points, 94 -> 128 x 7 -> 3: {t_fused:.3f} ms; PyTorch-ROCm: {t_torch:.3f} ms")
     assert t_fused < t_torch
+
+
+def test_device_packer_matches_the_pytorch_statement(hip_device):
+    """sr_mlp_pack == pack_layer_weight, plain and transposed blocks, with padding of rows, both column blocks and the bias."""
+    import ctypes as C
+    from splatfields_amd import _lib
+    from splatfields_amd.fused_mlp import pack_layer_weight
+    lib, dev = _lib.load(), hip_device
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(70, 94 + 128, generator=g).to(dev)          # [rows, input block | hidden block]
+    bias = torch.randn(70, generator=g).to(dev)
+    cases = [
+        # (transposed, row0, n_rows, n_mem, mem_pad, mem_col0, n_reg, reg_width, reg_col0, out_tiles, reference matrix)
+        (0, 0, 70, 94, 96, 0, 128, 128, 94, 5, W),
+        (0, 3, 40, 0, 0, 0, 100, 128, 10, 3, W[3:43, 10:110]),
+        (1, 94, 128, 70, 96, 0, 0, 0, 0, 8, W[:, 94:].t()),      # W[:, hidden block]^T: rows = hidden inputs, columns = outputs
+        (1, 16, 32, 0, 0, 0, 70, 96, 0, 2, W[:, 16:48].t()),
+    ]
+    jobs = (_lib.SrMlpPackJob * len(cases))()
+    outs, bouts = [], []
+    for j, (tr, row0, rows, n_mem, mem_pad, mc0, n_reg, rw, rc0, ot, _) in enumerate(cases):
+        outs.append(torch.full((16 * ot * (mem_pad + rw),), float("nan"), device=dev))
+        bouts.append(torch.full((16 * ot,), float("nan"), device=dev))
+        jobs[j] = _lib.SrMlpPackJob(w=W.data_ptr(), bias_src=bias.data_ptr(), dst=outs[j].data_ptr(), bias_dst=bouts[j].data_ptr(),
+                                    ld=W.stride(0), transposed=tr, row0=row0, n_rows=rows, n_mem=n_mem, mem_pad=mem_pad, mem_col0=mc0,
+                                    n_reg=n_reg, reg_width=rw, reg_col0=rc0, out_tiles=ot, n_bias=min(70, 16 * ot))
+    _lib.check(lib.sr_mlp_pack(len(cases), jobs, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    torch.cuda.synchronize()
+    for j, (tr, row0, rows, n_mem, mem_pad, mc0, n_reg, rw, rc0, ot, ref) in enumerate(cases):
+        want = pack_layer_weight(ref.contiguous(), n_mem, mem_pad, rw, ot)
+        assert torch.equal(outs[j], want), j
+        nb = min(70, 16 * ot)
+        assert torch.equal(bouts[j][:nb], bias[:nb]) and (bouts[j][nb:] == 0).all()
+    bad = (_lib.SrMlpPackJob * 1)()
+    bad[0] = jobs[0]
+    bad[0].mem_pad = 90                                           # not a multiple of 32
+    assert lib.sr_mlp_pack(1, bad, None) != 0
+
+
+GRAD_CASES = [(94, 128, 6, [3], 3), (82, 64, 4, [2], 3), (76, 64, 3, [20], 4), (33, 128, 1, [], 5), (130, 64, 2, [0, 1], 16),
+              (94, 128, 6, [3, 6], 128)]
+
+
+@pytest.mark.parametrize("d_in,hidden,n_hidden,skips,out", GRAD_CASES)
+@pytest.mark.parametrize("n,slope", [(777, 0.01), (2048, 0.2)])
+def test_fused_gradients_match_float64_autograd(hip_device, d_in, hidden, n_hidden, skips, out, n, slope):
+    from splatfields_amd.fused_mlp import fused_general_mlp
+    dev = hip_device
+    weights, biases = make_net(d_in, hidden, n_hidden, skips, out, dev, seed=7 + d_in + out)
+    g = torch.Generator().manual_seed(n)
+    h_in = torch.randn(n, d_in, generator=g).to(dev)
+    dY = torch.randn(n, out, generator=g).to(dev)
+
+    def leaves(dtype):
+        def leaf(t):
+            return t.detach().clone().to(dtype).requires_grad_()
+        return leaf(h_in), [leaf(w) for w in weights], [leaf(b) for b in biases]
+
+    x, ws, bs = leaves(torch.float32)
+    y = fused_general_mlp(x, ws, bs, skips=skips, negative_slope=slope)
+    y.backward(dY)
+    xr, wr, br = leaves(torch.float64)
+    yr = general_mlp_reference(xr, wr, br, set(skips), slope)
+    yr.backward(dY.double())
+    assert (y.double() - yr).abs().max().item() <= 2e-5 * yr.abs().max().item()
+    for name, got, ref in [("h_in", x, xr)] + [(f"W{j}", a, b) for j, (a, b) in enumerate(zip(ws, wr))] + \
+            [(f"b{j}", a, b) for j, (a, b) in enumerate(zip(bs, br))]:
+        assert got.grad is not None and got.grad.shape == ref.grad.shape, name
+        scale = ref.grad.abs().max().item()
+        err = (got.grad.double() - ref.grad).abs().max().item()
+        assert err <= 1e-4 * scale + 1e-12, (name, err, scale)
+
+
+def test_fused_gradients_flow_through_composed_weights(hip_device):
+    """ResField use: the effective weight W + (coefficients @ basis) is an autograd expression; dL/dW reaches both factors.
+    Gradients only for the tensors that ask for them; a second backward through the same graph is refused by autograd, a second
+    forward+backward gives the same numbers (deterministic kernels)."""
+    from splatfields_amd.fused_mlp import fused_general_mlp
+    dev = hip_device
+    weights, biases = make_net(94, 128, 3, [0], 3, dev, seed=3)
+    g = torch.Generator().manual_seed(1)
+    coeff = torch.randn(1, 10, generator=g).to(dev).requires_grad_()
+    basis = (0.01 * torch.randn(10, 128 * 128, generator=g)).to(dev).requires_grad_()
+    h_in = torch.randn(1500, 94, generator=g).to(dev)                    # no gradient wanted for the input
+    W1 = weights[1].clone().requires_grad_()
+
+    def run(fused):
+        for t in (coeff, basis, W1):
+            t.grad = None
+        ws = list(weights)
+        ws[1] = W1
+        ws[2] = weights[2] + (coeff @ basis).view(128, 128)
+        if fused:
+            y = fused_general_mlp(h_in, ws, biases, skips=[0])
+        else:
+            y = general_mlp_reference(h_in, ws, biases, {0}, 0.01)
+        (y ** 2).sum().backward()
+        return y.detach(), coeff.grad.clone(), basis.grad.clone(), W1.grad.clone()
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() <= 2e-4 * v.abs().max().item()
+    a2 = run(True)
+    for u, v in zip(a, a2):
+        assert torch.equal(u, v)
+    assert h_in.grad is None and weights[0].grad is None
+
+
+def test_fused_training_step_timing_vs_pytorch(hip_device):
+    """forward + backward of the deform-sized network on 100 k points, all gradients: fused vs layer-by-layer autograd (printed)."""
+    import time
+    from splatfields_amd.fused_mlp import fused_general_mlp
+    dev = hip_device
+    weights, biases = make_net(94, 128, 6, [3], 3, dev, seed=1)
+    for t in weights + biases:
+        t.requires_grad_()
+    h_in = torch.randn(100_000, 94, device=dev).requires_grad_()
+    dY = torch.randn(100_000, 3, device=dev)
+
+    def step(fused):
+        y = fused_general_mlp(h_in, weights, biases, skips=[3]) if fused else general_mlp_reference(h_in, weights, biases, {3}, 0.01)
+        torch.autograd.grad(y, [h_in] + weights + biases, dY)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 10 * 1e3
+
+    t_fused, t_torch = timed(lambda: step(True)), timed(lambda: step(False))
+    print(f"\nfused MLP forward+backward, 100k points, 94 -> 128 x 7 -> 3: {t_fused:.3f} ms; PyTorch-ROCm autograd: {t_torch:.3f} ms")
+    assert t_fused < t_torch
+
+
+@pytest.mark.parametrize("n", [50, 1000, 100_003])
+def test_weight_grad_kernel_matches_float64_products(hip_device, n):
+    """sr_mlp_weight_grad on its own: several jobs of different shapes in one launch, ragged point counts, padding columns
+    holding NaN (must not reach the results), bias sums, bit-identical repeats."""
+    import ctypes as C
+    from splatfields_amd import _lib
+    lib, dev = _lib.load(), hip_device
+    g = torch.Generator().manual_seed(n)
+    dz_a = torch.randn(n, 128, generator=g).to(dev)
+    dz_b = torch.zeros(n, 32, device=dev)
+    dz_b[:, :3] = torch.randn(n, 3, generator=g).to(dev)
+    dz_b[:, 3:] = float("nan")                                     # beyond m: dropped
+    x_in = torch.randn(n, 96, generator=g).to(dev)
+    x_in[:, 94:] = float("nan")                                    # beyond k: dropped
+    x_h = torch.randn(n, 128, generator=g).to(dev)
+    x_wide = torch.randn(n, 200, generator=g).to(dev)
+    dw1, db1 = torch.full((128, 94 + 128), 7.0, device=dev), torch.full((128,), 7.0, device=dev)
+    dw2, db2 = torch.full((3, 128), 7.0, device=dev), torch.full((3,), 7.0, device=dev)
+    dw3 = torch.full((128, 200), 7.0, device=dev)
+    J = _lib.SrMlpGradJob
+    jobs = (J * 4)(J(dz=dz_a.data_ptr(), x=x_in.data_ptr(), dw=dw1.data_ptr(), db=db1.data_ptr(), dz_row=128, m=128, x_row=96, k=94, dw_row=222, dw_col0=0),
+                   J(dz=dz_a.data_ptr(), x=x_h.data_ptr(), dw=dw1.data_ptr(), db=None, dz_row=128, m=128, x_row=128, k=128, dw_row=222, dw_col0=94),
+                   J(dz=dz_b.data_ptr(), x=x_h.data_ptr(), dw=dw2.data_ptr(), db=db2.data_ptr(), dz_row=32, m=3, x_row=128, k=128, dw_row=128, dw_col0=0),
+                   J(dz=dz_a.data_ptr(), x=x_wide.data_ptr(), dw=dw3.data_ptr(), db=None, dz_row=128, m=128, x_row=200, k=200, dw_row=200, dw_col0=0))
+    nbytes = lib.sr_mlp_weight_grad_workspace(n, 4, jobs)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run():
+        _lib.check(lib.sr_mlp_weight_grad(n, 4, jobs, C.c_void_p(ws.data_ptr()), nbytes, stream))
+        torch.cuda.synchronize()
+        return [t.clone() for t in (dw1, db1, dw2, db2, dw3)]
+
+    got = run()
+    a64, b64 = dz_a.double(), dz_b[:, :3].double()
+    want = [torch.cat([a64.t() @ x_in[:, :94].double(), a64.t() @ x_h.double()], 1), a64.sum(0), b64.t() @ x_h.double(), b64.sum(0),
+            a64.t() @ x_wide.double()]
+    for u, v in zip(got, want):
+        assert torch.isfinite(u).all()
+        assert (u.double() - v).abs().max().item() <= 2e-5 * v.abs().max().item() + 1e-6
+    for u, v in zip(got, run()):
+        assert torch.equal(u, v)
+    assert lib.sr_mlp_weight_grad(n, 4, jobs, C.c_void_p(ws.data_ptr()), nbytes - 16, stream) != 0     # workspace too small
