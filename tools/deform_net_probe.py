@@ -11,7 +11,8 @@ utils/resfields.py:378-405 (ResField linear layers: weight = base + per-frame lo
 points -- only the cost matters.  Runs on PyTorch-ROCm (rocBLAS / hipBLASLt / MIOpen), fp32 like the reference.
 
 Prints one JSON object: ms per forward+backward of the network for N splats, of the rasterizer (precomputed-colour path,
-reference train.py:80-81) for the same N, and the network's share of the step."""
+reference train.py:80-81) for the same N, the network's share of the step, and the same step with the six GeneralMLPs
+running through splatfields_amd.fused_mlp (forward and backward)."""
 import argparse
 import json
 import math
@@ -67,32 +68,30 @@ class GeneralMLP(nn.Module):
         self.out = ResLinear(hidden, out_features, rank, n_frames)
 
     def effective_weights(self, frame_id):
+        """per-step composed weights W + delta(frame) as autograd expressions (the ResField composition stays in PyTorch)"""
         ws, bs = [], []
         for layer in list(self.layers) + [self.out]:
             w = layer.lin.weight
             if layer.rank:
                 w = w + (layer.coef[frame_id] @ layer.basis).view_as(w)
-            ws.append(w.detach().contiguous()); bs.append(layer.lin.bias.detach())
+            ws.append(w); bs.append(layer.lin.bias)
         return ws, bs
 
     def forward_fused(self, xyz, feat, frame_id):
-        """the same network through splatfields_amd.fused_mlp (one kernel for all layers; inference only).  Note the layer
-        order of this stand-in: the skip input is concatenated BEHIND the hidden state here, in front of it in the reference
-        -- the fused kernel implements the reference's order, so the stand-in's skip weights are reordered on the way in."""
-        from splatfields_amd.fused_mlp import FusedGeneralMLP
-        key = int(frame_id)
-        if getattr(self, "_fused_key", None) != key:
-            ws, bs = self.effective_weights(frame_id)
-            hidden = ws[0].shape[0]
-            skips = []
-            for i in sorted(self.skips):
-                if 0 < i < len(ws):   # layer i consumes cat([h, h0]): move the h0 block in front
-                    ws[i] = torch.cat([ws[i][:, hidden:], ws[i][:, :hidden]], dim=1).contiguous()
-                    skips.append(i - 1)
-            self._fused = FusedGeneralMLP(ws, bs, self.d_in, skips, negative_slope=0.01)
-            self._fused_key = key
+        """the same network through splatfields_amd.fused_mlp (all layers in one kernel forward, one kernel for the activation
+        gradients + one for all weight gradients backward).  Note the layer order of this stand-in: the skip input is
+        concatenated BEHIND the hidden state here, in front of it in the reference -- the fused kernel implements the
+        reference's order, so the stand-in's skip weights are reordered on the way in."""
+        from splatfields_amd.fused_mlp import fused_general_mlp
+        ws, bs = self.effective_weights(frame_id)
+        hidden = ws[0].shape[0]
+        skips = []
+        for i in sorted(self.skips):
+            if 0 < i < len(ws):   # layer i consumes cat([h, h0]): move the h0 block in front
+                ws[i] = torch.cat([ws[i][:, hidden:], ws[i][:, :hidden]], dim=1)
+                skips.append(i - 1)
         h0 = torch.cat([posenc(xyz, self.multires), feat], dim=-1)
-        return self._fused(h0)
+        return fused_general_mlp(h0, ws, bs, skips=skips, negative_slope=0.01)
 
     def forward(self, xyz, feat, frame_id):
         h0 = torch.cat([posenc(xyz, self.multires), feat], dim=-1)
@@ -190,11 +189,19 @@ def main():
     rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.ones(3, device=dev), 1.0,
                                        cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False)
 
-    def net_step():
+    probes = {}
+
+    def net_step(fused=False, generic_loss=False):
         net.zero_grad(set_to_none=True)
         xyz.grad = None
-        out = net(xyz, 0.37)
-        loss = sum((v * v).mean() for v in out.values())
+        out = net(xyz, 0.37, fused=fused)
+        if generic_loss:   # fixed random cotangents: sum(v^2) is constant for the normalised rotations, whose gradients would be rounding noise
+            for k, v in out.items():
+                if k not in probes:
+                    probes[k] = torch.randn(v.shape, device=v.device, generator=torch.Generator(device=v.device).manual_seed(len(probes)))
+            loss = sum((v * probes[k]).mean() for k, v in out.items())
+        else:
+            loss = sum((v * v).mean() for v in out.values())
         loss.backward()
 
     def raster_step(out=None):
@@ -213,16 +220,37 @@ def main():
     def raster_only():
         raster_step({k: v.clone().requires_grad_(True) for k, v in fixed.items()})
 
-    def full_step():
+    def full_step(fused=False):
         net.zero_grad(set_to_none=True)
         xyz.grad = None
-        raster_step(net(xyz, 0.37))
+        raster_step(net(xyz, 0.37, fused=fused))
 
     res = {"splats": n, "image": [H, W], "net_parameters": n_params, "dtype": "fp32", "miopen_find": bool(a.miopen_find),
            "net_fwd_bwd_ms": timed(net_step, a.steps, 5), "rasterizer_fwd_bwd_ms": timed(raster_only, a.steps, 5),
            "full_step_ms": timed(full_step, a.steps, 5)}
     with torch.autocast("cuda", dtype=torch.bfloat16):
         res["net_fwd_bwd_ms_bf16_autocast"] = timed(net_step, a.steps, 5)
+    # training with the six GeneralMLPs through the fused kernels (fp32, same arithmetic): gradients of every parameter and of
+    # the positions against the PyTorch path, then the same timings
+    net_step(False, generic_loss=True)
+    ref_grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    ref_grads["xyz"] = xyz.grad.clone()
+    net_step(True, generic_loss=True)
+    got = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    got["xyz"] = xyz.grad
+    assert set(got) == set(ref_grads), sorted(set(got) ^ set(ref_grads))
+    diffs = {k: ((got[k] - g).abs().max() / g.abs().max().clamp_min(1e-20)).item() for k, g in ref_grads.items()}
+    worst = max(diffs, key=diffs.get)
+    res["fused_training_max_rel_grad_diff"] = diffs[worst]
+    res["fused_training_worst_tensor"] = worst
+    # per-point gradients (xyz) see leaky-ReLU units whose pre-activation sits within rounding of 0 take the other branch;
+    # parameter gradients sum over all points
+    res["fused_training_max_rel_grad_diff_parameters"] = max(v for k, v in diffs.items() if k != "xyz")
+    dx = (got["xyz"] - ref_grads["xyz"]).abs() / ref_grads["xyz"].abs().max()
+    res["fused_training_xyz_grad_frac_above_1e-4"] = (dx > 1e-4).float().mean().item()
+    res["fused_training_xyz_grad_median_rel_diff"] = dx.median().item()
+    res["net_fwd_bwd_fused_mlps_ms"] = timed(lambda: net_step(True), a.steps, 5)
+    res["full_step_fused_mlps_ms"] = timed(lambda: full_step(True), a.steps, 5)
     # inference (rendering a trained 4-D model, reference render.py): forward only, PyTorch layers vs the fused MLP kernel
     with torch.no_grad():
         ref_out = net(xyz, 0.37)
