@@ -246,6 +246,11 @@ def main():
     # per-point gradients (xyz) see leaky-ReLU units whose pre-activation sits within rounding of 0 take the other branch;
     # parameter gradients sum over all points
     res["fused_training_max_rel_grad_diff_parameters"] = max(v for k, v in diffs.items() if k != "xyz")
+    res["fused_training_worst_parameters"] = {k: diffs[k] for k in sorted((k for k in diffs if k != "xyz"), key=diffs.get, reverse=True)[:5]}
+    net_step(False, generic_loss=True)      # PyTorch against itself: the run-to-run noise of its own atomics (grid_sample backward, index_put)
+    again = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    res["pytorch_vs_pytorch_max_rel_grad_diff_parameters"] = max(((again[k] - g).abs().max() / g.abs().max().clamp_min(1e-20)).item()
+                                                                 for k, g in ref_grads.items() if k != "xyz")
     dx = (got["xyz"] - ref_grads["xyz"]).abs() / ref_grads["xyz"].abs().max()
     res["fused_training_xyz_grad_frac_above_1e-4"] = (dx > 1e-4).float().mean().item()
     res["fused_training_xyz_grad_median_rel_diff"] = dx.median().item()
