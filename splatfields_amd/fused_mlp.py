@@ -69,10 +69,6 @@ class _Shape:
                              if self.d_in - 16 * g > 0]
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
-
-
 class _Builder:
     """Collects pack jobs (one device launch) and the op list that uses their outputs."""
 
@@ -248,6 +244,18 @@ def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biase
         raise ValueError(f"h_in must be [N, {shape.d_in}]")
     if not (0.0 <= negative_slope < 1.0):
         raise ValueError("negative_slope must be in [0, 1)")
+    if len(biases) != shape.n_layers:
+        raise ValueError("one bias per layer")
+    for j, (W, b) in enumerate(zip(weights, biases)):
+        if tuple(b.shape) != (W.shape[0],):
+            raise ValueError(f"layer {j}: bias must be [{W.shape[0]}]")
+        for t in (W, b):
+            if t.device != h_in.device or t.dtype != torch.float32:
+                raise ValueError(f"layer {j}: weights and biases must be float32 tensors on {h_in.device}")
+    if h_in.dtype != torch.float32:
+        raise ValueError("h_in must be float32 (the reference network runs in fp32)")
+    if h_in.shape[0] == 0:      # nothing to launch; keep the graph connected so that parameters still receive (zero) gradients
+        return h_in.new_zeros(0, shape.out_features) + 0.0 * (h_in.sum() + sum(w.sum() for w in weights) + sum(b.sum() for b in biases))
     return _FusedMLPFn.apply(h_in, shape, float(negative_slope), *weights, *biases)
 
 

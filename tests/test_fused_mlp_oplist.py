@@ -119,3 +119,13 @@ def test_shape_validation():
         _Shape(w, 94, [0])                                                   # layer 1 would need 94 + 128 inputs
     with pytest.raises(ValueError):
         _Shape(w[:1], 94, [])
+
+
+def test_argument_validation_happens_before_any_launch(monkeypatch):
+    """bad arguments are refused by the host side (no GPU needed to see the message); CPU tensors are refused outright."""
+    from splatfields_amd import fused_mlp as fm, _lib
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    w = [torch.zeros(64, 20), torch.zeros(64, 64), torch.zeros(3, 64)]
+    b = [torch.zeros(64), torch.zeros(64), torch.zeros(3)]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fm.fused_general_mlp(torch.zeros(5, 20), w, b)
