@@ -36,8 +36,53 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMlpMaxOps = SR_MLP_MAX_OPS;
 struct MlpK { int n_ops; SrMlpOp op[kMlpMaxOps]; };
 
+// One 16-channel input tile (4 MFMA K steps) against all output tiles.  `w` points at this lane's float4 of output tile 0
+// (consecutive output tiles are 128 float4 apart).  FULL (every one of the HT output tiles is live, the common case): the LDS
+// reads of four output tiles are issued together and the MFMAs rotate over eight accumulators, so neither the LDS latency
+// nor the dependent accumulate chains stall the matrix pipe; otherwise tile by tile under a wave-uniform test.
+#ifndef SR_MLP_GROUP
+#define SR_MLP_GROUP 4      // output tiles whose LDS reads are issued together (the MFMAs rotate over 2 x this many accumulators)
+#endif
+#ifndef SR_MLP_WAVES8
+#define SR_MLP_WAVES8 2     // wavefronts per SIMD the 128-wide kernel is compiled for (256 / 168 VGPRs)
+#endif
+template <int HT, bool FULL>
+__device__ __forceinline__ void mlp_tile(f32x4 (&acc)[2][HT], const float4* w, int out_tiles, const f32x4 b0, const f32x4 b1) {
+    if constexpr (FULL) {
+#pragma unroll
+        for (int h = 0; h < HT; h += SR_MLP_GROUP) {
+            float4 a[SR_MLP_GROUP];
+#pragma unroll
+            for (int m = 0; m < SR_MLP_GROUP; ++m) a[m] = w[(h + m) * 128];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < SR_MLP_GROUP; ++m) {
+                    const float av = i == 0 ? a[m].x : i == 1 ? a[m].y : i == 2 ? a[m].z : a[m].w;
+                    acc[0][h + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[i], acc[0][h + m], 0, 0, 0);
+                    acc[1][h + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[i], acc[1][h + m], 0, 0, 0);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+            if (mt < out_tiles) {
+                const float4 a4 = w[mt * 128];
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0[0], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1[0], acc[1][mt], 0, 0, 0);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0[1], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1[1], acc[1][mt], 0, 0, 0);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0[2], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1[2], acc[1][mt], 0, 0, 0);
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0[3], acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1[3], acc[1][mt], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int HT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mlp_chain(const MlpK net, int n_points, float slope) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT == 8 ? SR_MLP_WAVES8 : 3, HT == 8 ? SR_MLP_WAVES8 : 3))) k_mlp_chain(const MlpK net, int n_points, float slope) {
     __shared__ float4 s_w[2][HT * 2 * 64];   // two chunks of a packed matrix: [mt][tl][lane]
     const int wave = wave_id(), lane = lane_id();
     const int k = lane >> 4, n = lane & 15;
@@ -73,28 +118,24 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
         stage(0, buf);
         int c = 0;
         // ---- input channels that come from memory (the network input / skip connection; the top gradient) ----
+        const bool full = L.out_tiles == HT;                   // wave-uniform
+        const bool store_vec = (L.store_row & 3) == 0 && (reinterpret_cast<uintptr_t>(L.store) & 15u) == 0;
         for (; c < L.mem_tiles / 2; ++c) {
+            // this chunk's input channels: both tiles' loads go out before the barrier and the staging of the next chunk
+            f32x4 bm[2][2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(L.src + (size_t)prow[nt] * L.src_row + 16 * (2 * c + tl) + 4 * k);
+                    bm[tl][nt] = (f32x4){t4.x, t4.y, t4.z, t4.w};
+                }
             __syncthreads();      // chunk c has landed; the other buffer is free
             if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
-                const int t = 2 * c + tl;
-                float4 b4[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) b4[nt] = *reinterpret_cast<const float4*>(L.src + (size_t)prow[nt] * L.src_row + 16 * t + 4 * k);
-#pragma unroll
-                for (int mt = 0; mt < HT; ++mt) {
-                    if (mt < L.out_tiles) {
-                        const float4 a4 = s_w[buf][(mt * 2 + tl) * 64 + lane];
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4[nt].x, acc[nt][mt], 0, 0, 0);
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4[nt].y, acc[nt][mt], 0, 0, 0);
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4[nt].z, acc[nt][mt], 0, 0, 0);
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4[nt].w, acc[nt][mt], 0, 0, 0);
-                        }
-                    }
-                }
+                if (full) mlp_tile<HT, true>(acc, &s_w[buf][tl * 64 + lane], L.out_tiles, bm[tl][0], bm[tl][1]);
+                else mlp_tile<HT, false>(acc, &s_w[buf][tl * 64 + lane], L.out_tiles, bm[tl][0], bm[tl][1]);
             }
             buf ^= 1;
         }
@@ -107,19 +148,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
                     const int t = 2 * cr + tl;
-#pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) {
-                        if (mt < L.out_tiles) {
-                            const float4 a4 = s_w[buf][(mt * 2 + tl) * 64 + lane];
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt) {
-                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, prev[nt][t][0], acc[nt][mt], 0, 0, 0);
-                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, prev[nt][t][1], acc[nt][mt], 0, 0, 0);
-                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, prev[nt][t][2], acc[nt][mt], 0, 0, 0);
-                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, prev[nt][t][3], acc[nt][mt], 0, 0, 0);
-                            }
-                        }
-                    }
+                    if (full) mlp_tile<HT, true>(acc, &s_w[buf][tl * 64 + lane], L.out_tiles, prev[0][t], prev[1][t]);
+                    else mlp_tile<HT, false>(acc, &s_w[buf][tl * 64 + lane], L.out_tiles, prev[0][t], prev[1][t]);
                 }
                 buf ^= 1;
                 ++c;
@@ -143,9 +173,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 
                     }
                     if (L.store && pvalid[nt]) {
                         float* dst = L.store + (size_t)(p0 + 16 * nt + n) * L.store_row + 16 * mt + 4 * k;
+                        if (store_vec && 16 * mt + 4 * k + 3 < L.store_channels) {       // whole float4 inside the row: one 16-byte access
+                            float4 v = make_float4(r[0], r[1], r[2], r[3]);
+                            if (L.store_accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            *reinterpret_cast<float4*>(dst) = v;
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (16 * mt + 4 * k + i < L.store_channels) dst[i] = L.store_accumulate ? dst[i] + r[i] : r[i];
+                            for (int i = 0; i < 4; ++i)
+                                if (16 * mt + 4 * k + i < L.store_channels) dst[i] = L.store_accumulate ? dst[i] + r[i] : r[i];
+                        }
                     }
                 }
                 if (!L.keep_state) prev[nt][mt] = r;
