@@ -395,7 +395,8 @@ int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* o
     for (int l = 0; l < n_ops; ++l) {
         const SrMlpOp& s = ops[l];
         if (s.out_tiles < 1 || s.out_tiles > hidden_tiles || s.mem_tiles < 0 || s.reg_tiles < 0 || s.reg_tiles > hidden_tiles ||
-            (s.mem_tiles & 1) || (s.reg_tiles & 1) || s.mem_tiles + s.reg_tiles < 2 || !s.w_packed) return 1;
+            (s.mem_tiles & 1) || (s.reg_tiles & 1) || s.mem_tiles + s.reg_tiles < 2 || !s.w_packed ||
+            (reinterpret_cast<uintptr_t>(s.w_packed) & 15u) || (reinterpret_cast<uintptr_t>(s.bias) & 15u)) return 1;
         if (s.mem_tiles > 0 && (!s.src || s.mem_tiles * 16 > s.src_row || (s.src_row & 3) || (reinterpret_cast<uintptr_t>(s.src) & 15u))) return 1;
         if (s.epilogue != SR_MLP_NONE && s.epilogue != SR_MLP_LEAKY && s.epilogue != SR_MLP_MASK) return 1;
         if (s.epilogue == SR_MLP_MASK && (!s.mask || s.out_tiles * 16 > s.mask_row || (s.mask_row & 3) || (reinterpret_cast<uintptr_t>(s.mask) & 15u))) return 1;

@@ -217,6 +217,7 @@ class _FusedMLPFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dY):
         shape, slope = ctx.shape, ctx.slope
         x0, acts, y, *weights = ctx.saved_tensors

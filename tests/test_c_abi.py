@@ -104,3 +104,38 @@ def test_header_constants_match_the_binding():
     assert (defs["SR_MLP_MAX_GRAD_JOBS"], defs["SR_MLP_MAX_GRAD_TASKS"]) == (_lib.MLP_MAX_GRAD_JOBS, _lib.MLP_MAX_GRAD_TASKS)
     assert (defs["SR_MLP_MAX_OPS"], defs["SR_MLP_NONE"], defs["SR_MLP_LEAKY"], defs["SR_MLP_MASK"]) == \
         (_lib.MLP_MAX_OPS, _lib.MLP_NONE, _lib.MLP_LEAKY, _lib.MLP_MASK)
+
+
+def test_mlp_entry_points_refuse_bad_descriptions_without_touching_a_device():
+    """argument validation of sr_mlp_chain / sr_mlp_pack / sr_mlp_weight_grad happens on the host before any launch."""
+    from splatfields_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_float * 4096)()
+    base = C.addressof(buf)
+    base += (-base) % 16
+    op = _lib.SrMlpOp(w_packed=base, bias=None, src=base, mask=None, store=None, out_tiles=8, mem_tiles=2, reg_tiles=0, src_row=32,
+                      epilogue=_lib.MLP_LEAKY, mask_row=0, store_row=0, store_channels=0, store_accumulate=0, keep_state=0)
+    ops = (_lib.SrMlpOp * 1)(op)
+    assert lib.sr_mlp_chain(-1, 8, 1, ops, 0.01, None) != 0
+    assert lib.sr_mlp_chain(0, 8, 1, ops, 1.5, None) != 0 and b"negative_slope" in lib.sr_last_error()
+    assert lib.sr_mlp_chain(0, 8, 0, ops, 0.01, None) != 0
+    assert lib.sr_mlp_chain(0, 8, _lib.MLP_MAX_OPS + 1, ops, 0.01, None) != 0
+    assert lib.sr_mlp_chain(0, 6, 1, ops, 0.01, None) != 0 and b"unsupported op list" in lib.sr_last_error()   # out_tiles 8 > hidden_tiles 6
+    for field, bad in [("mem_tiles", 3), ("src_row", 16), ("epilogue", 7), ("w_packed", base + 4), ("out_tiles", 0)]:
+        broken = (_lib.SrMlpOp * 1)(op)
+        setattr(broken[0], field, bad)
+        assert lib.sr_mlp_chain(0, 8, 1, broken, 0.01, None) != 0 and b"unsupported op list" in lib.sr_last_error(), field
+    masked = (_lib.SrMlpOp * 1)(op)
+    masked[0].epilogue = _lib.MLP_MASK                                           # mask epilogue without a mask pointer
+    assert lib.sr_mlp_chain(0, 8, 1, masked, 0.01, None) != 0 and b"unsupported op list" in lib.sr_last_error()
+    assert lib.sr_mlp_pack(_lib.MLP_MAX_PACK_JOBS + 1, (_lib.SrMlpPackJob * 1)(), None) != 0 and b"sr_mlp_pack" in lib.sr_last_error()
+    J = _lib.SrMlpGradJob
+    good = (J * 2)(J(dz=base, x=base, dw=base, db=None, dz_row=128, m=128, x_row=96, k=94, dw_row=222, dw_col0=0),
+                   J(dz=base, x=base, dw=base, db=base, dz_row=32, m=3, x_row=128, k=128, dw_row=128, dw_col0=0))
+    # 2 x 2 + 1 x 2 blocks of 64 x 64, 256 slabs of 392 points, (4096 + 64) floats per block and slab
+    assert lib.sr_mlp_weight_grad_workspace(100_000, 2, good) == 6 * 256 * (4096 + 64) * 4
+    assert lib.sr_mlp_weight_grad_workspace(50, 2, good) == 6 * 1 * (4096 + 64) * 4
+    bad = (J * 1)(J(dz=base, x=base, dw=base, db=None, dz_row=126, m=100, x_row=96, k=94, dw_row=94, dw_col0=0))   # row stride not a multiple of 4
+    assert lib.sr_mlp_weight_grad_workspace(1000, 1, bad) == 0
+    assert lib.sr_mlp_weight_grad(1000, 1, bad, base, 1 << 30, None) != 0 and b"unsupported job list" in lib.sr_last_error()
+    assert lib.sr_mlp_weight_grad(0, 2, good, base, 1 << 30, None) != 0
