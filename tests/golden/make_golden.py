@@ -12,6 +12,11 @@ reference checkout exists at /root/reference; the fixtures (pure numbers) are wh
                       second pass, output dict keys / shapes / dtypes).
   tiny_*.npz       -- small scenes: inputs + fp64 torch-oracle outputs and gradients (regression pins for both
                       oracles and for the HIP path).
+  general_mlp_*.npz -- the reference's GeneralMLP (utils/time_utils.py:123-191, with the ResField layers of
+                      utils/resfields.py) imported and run on CPU in float32: its state dict, inputs, frame id, output
+                      and the gradients of sum(output * probe) w.r.t. the inputs and every parameter, for the shapes
+                      SplatFields builds (scaled down).  scene.tripFields (diffusers / mmgen, absent here) is not needed by
+                      GeneralMLP and is kept out of the import.
 """
 import json
 import math
@@ -198,7 +203,70 @@ def tiny_scenes():
         print(name, "R =", out.num_rendered, "fragile px =", int(out.fragile.sum()))
 
 
+GENERAL_MLP_CASES = {
+    # name: (constructor kwargs, feature channels, frame id or None)
+    "scale": (dict(in_features=3 + 8 + 7, out_features=3, hidden_features=64, num_hidden_layers=4, skips=[2], multires=4,
+                   out_activation="none", act="leaky_relu", composition_rank=2, n_frames=10), 15, 3),
+    "opacity": (dict(in_features=3 + 8 + 7, out_features=1, hidden_features=64, num_hidden_layers=4, skips=[2], multires=3,
+                     out_activation="sigmoid", act="leaky_relu", composition_rank=1, n_frames=6), 15, 5),
+    "rotation": (dict(in_features=3 + 8 + 7, out_features=4, hidden_features=64, num_hidden_layers=3, skips=[20], multires=3,
+                      out_activation="normalize", act="leaky_relu", composition_rank=1, n_frames=4), 15, 0),
+    "deform": (dict(in_features=3 + 16 + 7, out_features=3, hidden_features=128, num_hidden_layers=3, skips=[1], multires=6,
+                    out_activation="none", act="leaky_relu", composition_rank=1, n_frames=5), 23, 4),
+    "static_rgb": (dict(in_features=3 + 8, out_features=3, hidden_features=64, num_hidden_layers=2, skips=[0], multires=2,
+                        out_activation="sigmoid", act="leaky_relu", composition_rank=0, n_frames=0), 8, None),
+    "no_features": (dict(in_features=3, out_features=5, hidden_features=64, num_hidden_layers=2, skips=[4], multires=0,
+                         out_activation="tanh", act="relu", composition_rank=0, n_frames=0), 0, None),
+}
+
+
+def general_mlp_cases():
+    """imports utils/time_utils.py with scene.tripFields masked out (GeneralMLP does not use it; its own imports -- diffusers,
+    mmgen -- do not exist here)"""
+    sys.path.insert(0, REF)
+    scene_pkg = types.ModuleType("scene")
+    scene_pkg.__path__ = []
+    masked = types.ModuleType("scene.tripFields")
+    for name in ["TriPlaneEncoder", "VarTriPlaneEncoder", "HexPlaneEncoder", "VarHexPlaneEncoder", "GridEncoder", "VarGridEncoder",
+                 "LaplaceDensity", "BellDensity"]:
+        setattr(masked, name, object)
+    saved = {k: sys.modules.get(k) for k in ("scene", "scene.tripFields")}
+    sys.modules["scene"], sys.modules["scene.tripFields"] = scene_pkg, masked
+    try:
+        from utils.time_utils import GeneralMLP
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    for idx, (name, (kwargs, n_feat, frame)) in enumerate(GENERAL_MLP_CASES.items()):
+        torch.manual_seed(100 + idx)
+        net = GeneralMLP(**kwargs)
+        with torch.no_grad():                      # default init leaves the residuals at 1e-2 scale; make them matter
+            for k, p in net.named_parameters():
+                if k.endswith("matrix_t") or k.endswith("weights_t"):
+                    p.mul_(30.0)
+        n = 40
+        xyz = (torch.rand(n, 3) * 2 - 1).requires_grad_()
+        feat = torch.randn(n, n_feat).requires_grad_() if n_feat else None
+        frame_id = None if frame is None else torch.tensor(frame)
+        out = net(xyz, feat, frame_id=frame_id)
+        probe = torch.randn(out.shape)
+        (out * probe).sum().backward()
+        data = {"xyz": xyz.detach().numpy(), "out": out.detach().numpy(), "probe": probe.numpy(), "grad_xyz": xyz.grad.numpy(),
+                "frame_id": np.array(-1 if frame is None else frame)}
+        if feat is not None:
+            data["feat"], data["grad_feat"] = feat.detach().numpy(), feat.grad.numpy()
+        for k, p in net.named_parameters():
+            data["param:" + k] = p.detach().numpy()
+            data["grad:" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        np.savez_compressed(os.path.join(HERE, f"general_mlp_{name}.npz"), **data)
+        print(name, tuple(out.shape), sum(v.size for v in data.values()), "floats")
+
+
 if __name__ == "__main__":
-    ref_pieces()
-    render_contract()
-    tiny_scenes()
+    only = sys.argv[1:]          # e.g. `make_golden.py general_mlp_cases` regenerates one family
+    for fn in (ref_pieces, render_contract, tiny_scenes, general_mlp_cases):
+        if not only or fn.__name__ in only:
+            fn()
