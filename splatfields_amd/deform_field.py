@@ -1,0 +1,172 @@
+"""Counterpart of the reference's `SplatFields` network (utils/time_utils.py:305-508) with its six `GeneralMLP`s on the fused
+kernels (splatfields_amd/general_mlp.py).
+
+Same constructor keywords, same `forward(xyz_in, t)` -> dict(scales, opacity, rotations, rgb | rgb_fnc, flow, means3D), same
+parameter names (`mlp_deform.net.<i>...`, `mlp_refine_feat.<i>...`, `mlp_flow_head.branch_w...`, `encoder....`), so
+`deform.pth` checkpoints (reference scene/deform_model.py:36-47) load with `load_state_dict`.
+
+What is NOT here is the tri-plane feature encoder (reference scene/tripFields.py: a diffusers / mmgen VAE decoder that
+produces the planes; those packages exist neither in the reference checkout nor in this image): pass any module with
+the encoder's interface -- `encoder(x[None]) -> [1, N, out_dim]`, attribute `out_dim` -- e.g. the reference's own
+`VarTriPlaneEncoder` instance; with `encoder=None` the network runs without plane features, which is the reference's
+behaviour for an `encoder_type` outside its list (`feat_dim = 0`, utils/time_utils.py:333-334).
+
+`FlowHead` (utils/time_utils.py:194-303): 'offset', 'se3' (default) and 'dct'; the SE(3) exponential is written out per point
+(no 4x4 batched matmuls), following the reference's formulas including its `w / theta + 1e-5` convention.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .general_mlp import GeneralMLP, positional_encoding
+
+
+def _cross(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return torch.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], dim=-1)
+
+
+def se3_transform(w: torch.Tensor, v: torch.Tensor, theta: torch.Tensor):
+    """exp of the screw (w, v) * theta as the reference builds it (utils/rigid_utils.py:40-84; Modern Robotics 3.51 / 3.88),
+    without assuming |w| = 1 (the reference adds 1e-5 to the normalised axis):  R = I + sin(theta) [w] + (1 - cos(theta)) [w]^2,
+    p = (theta I + (1 - cos(theta)) [w] + (theta - sin(theta)) [w]^2) v, with [w]^2 = w w^T - |w|^2 I.  -> [N, 4, 4]."""
+    n = w.shape[0]
+    s, c = torch.sin(theta), torch.cos(theta)                    # [N, 1]
+    zeros = torch.zeros(n, device=w.device, dtype=w.dtype)
+    skew = torch.stack([zeros, -w[:, 2], w[:, 1], w[:, 2], zeros, -w[:, 0], -w[:, 1], w[:, 0], zeros], dim=-1).view(n, 3, 3)
+    eye = torch.eye(3, device=w.device, dtype=w.dtype).expand(n, 3, 3)
+    skew2 = w[:, :, None] * w[:, None, :] - (w * w).sum(-1)[:, None, None] * eye
+    R = eye + s[:, :, None] * skew + (1.0 - c)[:, :, None] * skew2
+    wv = _cross(w, v)
+    wwv = _cross(w, wv)
+    p = theta * v + (1.0 - c) * wv + (theta - s) * wwv
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=w.device, dtype=w.dtype).expand(n, 1, 4)
+    return torch.cat([torch.cat([R, p[:, :, None]], dim=-1), bottom], dim=1)
+
+
+def dct_basis(num_basis: int, num_frames: int) -> torch.Tensor:
+    """reference utils/time_utils.py:60-70: sqrt(2 / T) cos(pi / (2 T) (2 t + 1) k), k = 1..K"""
+    t = torch.arange(num_frames, dtype=torch.float64)[:, None]
+    k = torch.arange(1, num_basis + 1, dtype=torch.float64)[None, :]
+    return (math.sqrt(2.0 / num_frames) * torch.cos(math.pi / (2.0 * num_frames) * (2 * t + 1) * k)).to(torch.float32)
+
+
+class FlowHead(nn.Module):
+    def __init__(self, W: int = 256, flow_model: str = "offset", num_basis: int = 4, n_frames: int = 100):
+        super().__init__()
+        self.W, self.flow_model, self.n_frames, self.num_basis = W, flow_model, n_frames, num_basis
+        if flow_model == "offset":
+            self.gaussian_warp = nn.Linear(W, 3)
+        elif flow_model == "se3":
+            self.branch_w = nn.Linear(W, 3)
+            self.branch_v = nn.Linear(W, 3)
+        elif flow_model == "dct":
+            self.branch_coeff = nn.Linear(W, 3 * num_basis)
+            nn.init.zeros_(self.branch_coeff.weight)
+            nn.init.zeros_(self.branch_coeff.bias)
+            self.trajectory_basis = nn.Parameter(dct_basis(num_basis, n_frames * 2))
+        else:
+            raise NotImplementedError(f"flow_model={flow_model!r}: offset, se3 and dct are implemented")
+
+    def forward(self, hidden, pts, time_step=None, frame_id=None):
+        if self.flow_model == "offset":
+            flow = self.gaussian_warp(hidden)
+            return flow, pts + flow
+        if self.flow_model == "se3":
+            w, v = self.branch_w(hidden), self.branch_v(hidden)
+            theta = torch.norm(w, dim=-1, keepdim=True)
+            w = w / theta + 1e-5
+            v = v / theta + 1e-5
+            flow = se3_transform(w, v, theta)
+            means3D = (flow[:, :3, :3] * pts[:, None, :]).sum(-1) + flow[:, :3, 3]
+            return flow, means3D
+        coeff = self.branch_coeff(hidden).view(-1, 3, self.num_basis)
+        bases = self.trajectory_basis[frame_id.long() if torch.is_tensor(frame_id) else int(frame_id)]
+        flow = (coeff * bases.view(1, 1, -1)).sum(-1)
+        return flow, pts + flow
+
+
+class SplatFields(nn.Module):
+    def __init__(self, radius=None, n_frames: int = 0, encoder: Optional[nn.Module] = None, **kwargs):
+        super().__init__()
+        rank = kwargs.get("composition_rank", 0)
+        self.n_frames = n_frames
+        self.encoder_type = kwargs.get("encoder_type", "VarTriPlaneEncoder")
+        if encoder is not None:
+            self.encoder = encoder
+            self.feat_dim = int(encoder.out_dim)
+            self.mlp_refine_feat = nn.Sequential(nn.Linear(self.feat_dim, self.feat_dim), nn.ReLU(), nn.Linear(self.feat_dim, self.feat_dim))
+        elif self.encoder_type in ["VarTriPlaneEncoder"]:
+            raise NotImplementedError("the tri-plane encoder (reference scene/tripFields.py, a diffusers / mmgen decoder) is not part of "
+                                      "this library: pass it as `encoder=` or choose another encoder_type to run without plane features")
+        else:
+            self.feat_dim = 0
+        if n_frames > 0:
+            self.time_multires = kwargs.get("time_multires", 3)
+            time_ch = 1 + 2 * self.time_multires
+        else:
+            self.time_multires, time_ch = 0, 0
+        self.deform_weight = kwargs.get("deform_weight", 1.0)
+        in_ch = 3 + self.feat_dim + time_ch
+
+        def mlp(prefix, out, w, d, skips, multires, out_act, in_features=in_ch):
+            return GeneralMLP(in_features=in_features, out_features=out, hidden_features=kwargs.get(prefix + "_w", w),
+                              num_hidden_layers=kwargs.get(prefix + "_d", d), skips=kwargs.get(prefix + "_skips", skips),
+                              multires=multires, out_activation=out_act, act="leaky_relu", composition_rank=rank, n_frames=n_frames)
+
+        self.mlp_deform = mlp("deform", 3, 128, 6, [3], kwargs.get("deform_multires", 6), "none")
+        self.use_view_dep_rgb = kwargs.get("use_view_dep_rgb", False)
+        self.mlp_rgb = mlp("rgb", kwargs.get("rgb_w", 128) if self.use_view_dep_rgb else 3, 128, 6, [3], kwargs.get("rgb_multires", 6),
+                           "none" if self.use_view_dep_rgb else "sigmoid")
+        if self.use_view_dep_rgb:
+            self.mlp_rgb_viewdep = nn.Sequential(nn.Linear(3 + self.mlp_rgb.out_features, 3), nn.Sigmoid())
+        self.geo_model_disable_pts = bool(kwargs.get("geo_model_disable_pts", False))
+        geo_in = in_ch - (3 if self.geo_model_disable_pts else 0)
+        off = self.geo_model_disable_pts
+        self.mlp_scale = mlp("scale", 3, 64, 4, [2], 0 if off else kwargs.get("scale_multires", 4), "none", geo_in)
+        self.mlp_opacity = mlp("opacity", 1, 64, 4, [2], 0 if off else kwargs.get("opacity_multires", 3), "sigmoid", geo_in)
+        self.mlp_rotation = mlp("rotation", 4, 64, 3, [20], 0 if off else kwargs.get("rotation_multires", 3), "normalize", geo_in)
+        if n_frames > 0:
+            self.mlp_flow = mlp("flow", kwargs.get("flow_w", 128), 128, 6, [3], kwargs.get("flow_multires", 6), "none")
+            self.mlp_flow_head = FlowHead(W=self.mlp_flow.out_features, flow_model=kwargs.get("flow_model", "se3"),
+                                          num_basis=kwargs.get("dct_basis", 4), n_frames=n_frames)
+
+    def _time2frame_id(self, t):
+        return torch.round(t * (self.n_frames - 1))
+
+    def extract_features(self, x, t):
+        t_feat = positional_encoding(t, self.time_multires) if self.n_frames > 0 else None
+        x_feat = self.mlp_refine_feat(self.encoder(x[None]).squeeze(0)) if self.feat_dim > 0 else None
+        parts = [f for f in (x_feat, t_feat) if f is not None]
+        return torch.cat(parts, dim=-1) if parts else None
+
+    def forward(self, xyz_in, t):
+        out = {}
+        time_step, frame_id = None, None
+        if self.n_frames > 0:
+            time_step = t.view(-1)[0]
+            frame_id = self._time2frame_id(time_step).long()
+        feat = self.extract_features(xyz_in, t)
+        if self.deform_weight > 0:
+            xyz_can = xyz_in + self.deform_weight * self.mlp_deform(xyz_in, feat, frame_id=frame_id)
+        else:
+            xyz_can = xyz_in
+        geo_xyz, geo_feat = (feat, None) if self.geo_model_disable_pts else (xyz_can, feat)
+        out["scales"] = self.mlp_scale(geo_xyz, geo_feat, frame_id=frame_id)
+        out["opacity"] = self.mlp_opacity(geo_xyz, geo_feat, frame_id=frame_id)
+        out["rotations"] = self.mlp_rotation(geo_xyz, geo_feat, frame_id=frame_id)
+        rgb = self.mlp_rgb(xyz_can, feat, frame_id=frame_id)
+        if self.use_view_dep_rgb:
+            out["rgb_fnc"] = lambda viewdir: self.mlp_rgb_viewdep(torch.cat([rgb, viewdir], dim=-1))
+        else:
+            out["rgb"] = rgb
+        if self.n_frames > 0:
+            flow_feat = self.mlp_flow(xyz_can, feat, frame_id=frame_id)
+            flow, means3D = self.mlp_flow_head(hidden=flow_feat, pts=xyz_can, time_step=time_step, frame_id=frame_id)
+        else:
+            flow, means3D = None, xyz_can
+        out.update({"flow": flow, "means3D": means3D})
+        return out

@@ -17,6 +17,9 @@ reference checkout exists at /root/reference; the fixtures (pure numbers) are wh
                       and the gradients of sum(output * probe) w.r.t. the inputs and every parameter, for the shapes
                       SplatFields builds (scaled down).  scene.tripFields (diffusers / mmgen, absent here) is not needed by
                       GeneralMLP and is kept out of the import.
+  splatfields_*.npz -- the reference's whole SplatFields network (utils/time_utils.py:305-508: six GeneralMLPs, time embedding,
+                      FlowHead) in configurations without plane features, same contents as above for every output of
+                      forward(xyz, t).
 """
 import json
 import math
@@ -220,9 +223,9 @@ GENERAL_MLP_CASES = {
 }
 
 
-def general_mlp_cases():
-    """imports utils/time_utils.py with scene.tripFields masked out (GeneralMLP does not use it; its own imports -- diffusers,
-    mmgen -- do not exist here)"""
+def import_time_utils():
+    """imports utils/time_utils.py with scene.tripFields masked out (GeneralMLP / FlowHead / SplatFields without plane
+    features do not use it; its own imports -- diffusers, mmgen -- do not exist here)"""
     sys.path.insert(0, REF)
     scene_pkg = types.ModuleType("scene")
     scene_pkg.__path__ = []
@@ -233,13 +236,18 @@ def general_mlp_cases():
     saved = {k: sys.modules.get(k) for k in ("scene", "scene.tripFields")}
     sys.modules["scene"], sys.modules["scene.tripFields"] = scene_pkg, masked
     try:
-        from utils.time_utils import GeneralMLP
+        from utils import time_utils
     finally:
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+    return time_utils
+
+
+def general_mlp_cases():
+    GeneralMLP = import_time_utils().GeneralMLP
     for idx, (name, (kwargs, n_feat, frame)) in enumerate(GENERAL_MLP_CASES.items()):
         torch.manual_seed(100 + idx)
         net = GeneralMLP(**kwargs)
@@ -265,8 +273,65 @@ def general_mlp_cases():
         print(name, tuple(out.shape), sum(v.size for v in data.values()), "floats")
 
 
+_SMALL = dict(deform_w=64, deform_d=2, deform_skips=[1], rgb_w=64, rgb_d=2, rgb_skips=[0], flow_w=64, flow_d=2, flow_skips=[1],
+              scale_d=2, scale_skips=[0], opacity_d=2, opacity_skips=[5], rotation_d=2, encoder_type="none")
+SPLATFIELDS_CASES = {
+    # name: (n_frames, constructor kwargs, time value): networks without plane features (the tri-plane encoder cannot be imported here)
+    "dynamic_se3": (5, dict(_SMALL, composition_rank=1, flow_model="se3"), 0.75),
+    "dynamic_dct": (6, dict(_SMALL, composition_rank=0, flow_model="dct", dct_basis=3, deform_weight=0.5), 0.4),
+    "static_viewdep": (0, dict(_SMALL, composition_rank=0, use_view_dep_rgb=True), 0.0),
+}
+
+
+def splatfields_cases():
+    """the reference's SplatFields.forward (utils/time_utils.py:467-508) without plane features: state dict, positions, time,
+    every output and the gradients of sum over outputs of (output * probe)."""
+    SplatFields = import_time_utils().SplatFields
+    for idx, (name, (n_frames, kwargs, tval)) in enumerate(SPLATFIELDS_CASES.items()):
+        torch.manual_seed(200 + idx)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):            # the constructor prints the module
+            net = SplatFields(radius=None, n_frames=n_frames, **kwargs)
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                if k.endswith("matrix_t") or k.endswith("weights_t"):
+                    p.mul_(30.0)
+                if "branch_coeff" in k:                               # zero-initialised in the reference; make the dct path matter
+                    p.normal_(0.0, 0.1)
+        n = 32
+        xyz = (torch.rand(n, 3) * 2 - 1).requires_grad_()
+        t = torch.full((n, 1), tval)
+        out = net(xyz, t)
+        if "rgb_fnc" in out:
+            viewdir = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+            out = dict(out, rgb=out["rgb_fnc"](viewdir))
+            del out["rgb_fnc"]
+        else:
+            viewdir = None
+        data = {"xyz": xyz.detach().numpy(), "t": t.numpy()}
+        if viewdir is not None:
+            data["viewdir"] = viewdir.numpy()
+        loss = 0.0
+        for k in sorted(out):
+            if out[k] is None:
+                continue
+            probe = torch.randn(out[k].shape)
+            loss = loss + (out[k] * probe).sum()
+            data["out:" + k], data["probe:" + k] = out[k].detach().numpy(), probe.numpy()
+        loss.backward()
+        data["grad_xyz"] = xyz.grad.numpy()
+        for k, p in net.named_parameters():
+            data["param:" + k] = p.detach().numpy()
+            data["grad:" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        for k, b in net.named_buffers():
+            data["param:" + k] = b.detach().numpy()
+        np.savez_compressed(os.path.join(HERE, f"splatfields_{name}.npz"), **data)
+        print(name, sorted(k for k in data if k.startswith("out:")), sum(v.size for v in data.values()), "floats")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]          # e.g. `make_golden.py general_mlp_cases` regenerates one family
-    for fn in (ref_pieces, render_contract, tiny_scenes, general_mlp_cases):
+    for fn in (ref_pieces, render_contract, tiny_scenes, general_mlp_cases, splatfields_cases):
         if not only or fn.__name__ in only:
             fn()

@@ -1,0 +1,122 @@
+"""splatfields_amd.deform_field.SplatFields against fixtures made by running the reference's SplatFields (utils/time_utils.py:305-508)
+on CPU without plane features -- tests/golden/make_golden.py: splatfields_cases.  Every output of forward(xyz, t) and the gradients
+of sum(output * probe) w.r.t. the positions and every parameter.
+
+* CPU: the network's host side (six GeneralMLPs wired as in the reference, time embedding, FlowHead incl. the SE(3) exponential,
+  view-dependent colour head, parameter names = the reference's state dict) with the fused MLP op replaced by its formula;
+* GPU: the same through the HIP kernels.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_general_mlp import GOLDEN, formula
+
+CASES = sorted(os.path.basename(p)[len("splatfields_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "splatfields_*.npz")))
+
+
+def case_config(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.SPLATFIELDS_CASES[name]
+
+
+def run_case(name, device, out_tol, grad_tol):
+    from splatfields_amd.deform_field import SplatFields
+    data = np.load(os.path.join(GOLDEN, f"splatfields_{name}.npz"))
+    n_frames, kwargs, _ = case_config(name)
+    net = SplatFields(radius=None, n_frames=n_frames, **kwargs)
+    state = {k[len("param:"):]: torch.from_numpy(data[k]) for k in data.files if k.startswith("param:")}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in state.items()}
+    net.load_state_dict(state, strict=True)
+    net = net.to(device)
+    xyz = torch.from_numpy(data["xyz"]).to(device).requires_grad_()
+    out = net(xyz, torch.from_numpy(data["t"]).to(device))
+    if "rgb_fnc" in out:
+        out = dict(out, rgb=out["rgb_fnc"](torch.from_numpy(data["viewdir"]).to(device)))
+        del out["rgb_fnc"]
+    expected = sorted(k[len("out:"):] for k in data.files if k.startswith("out:"))
+    assert sorted(k for k, v in out.items() if v is not None) == expected
+    loss = 0.0
+    for k in expected:
+        ref = torch.from_numpy(data["out:" + k])
+        assert out[k].shape == ref.shape, k
+        assert (out[k].detach().cpu() - ref).abs().max().item() <= out_tol * max(ref.abs().max().item(), 1e-6), k
+        loss = loss + (out[k] * torch.from_numpy(data["probe:" + k]).to(device)).sum()
+    loss.backward()
+    pairs = [("xyz", xyz.grad, data["grad_xyz"])]
+    for k, p in net.named_parameters():
+        pairs.append((k, p.grad if p.grad is not None else torch.zeros_like(p), data["grad:" + k]))
+    for k, got, want in pairs:
+        want = torch.from_numpy(want)
+        err = (got.detach().cpu() - want).abs().max().item()
+        assert err <= grad_tol * want.abs().max().item() + 1e-8, (k, err, want.abs().max().item())
+
+
+def test_fixtures_present():
+    assert set(CASES) >= {"dynamic_se3", "dynamic_dct", "static_viewdep"}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_host_side_matches_the_reference_network(monkeypatch, name):
+    from splatfields_amd import general_mlp
+    monkeypatch.setattr(general_mlp, "fused_general_mlp", formula)
+    run_case(name, torch.device("cpu"), 2e-5, 2e-4)
+
+
+def test_se3_transform_is_a_rigid_motion_for_unit_axes():
+    """known answers for the written-out exponential: unit axis -> orthonormal R with det 1; rotation about z by theta; pure
+    translation direction for the screw's linear part at small angles."""
+    from splatfields_amd.deform_field import se3_transform
+    g = torch.Generator().manual_seed(0)
+    w = torch.nn.functional.normalize(torch.randn(64, 3, generator=g, dtype=torch.float64), dim=-1)
+    v = torch.randn(64, 3, generator=g, dtype=torch.float64)
+    theta = torch.rand(64, 1, generator=g, dtype=torch.float64) * 3
+    T = se3_transform(w, v, theta)
+    R = T[:, :3, :3]
+    assert (R @ R.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max() < 1e-12
+    assert (torch.linalg.det(R) - 1).abs().max() < 1e-12
+    assert (T[:, 3] - torch.tensor([0, 0, 0, 1.0], dtype=torch.float64)).abs().max() == 0
+    z = torch.tensor([[0.0, 0.0, 1.0]], dtype=torch.float64)
+    Tz = se3_transform(z, torch.zeros(1, 3, dtype=torch.float64), torch.tensor([[0.5]], dtype=torch.float64))
+    c, s = np.cos(0.5), np.sin(0.5)
+    assert torch.allclose(Tz[0, :3, :3], torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=torch.float64), atol=1e-15)
+    # (w * theta) is the rotation vector: compare with the matrix exponential of the twist
+    twist = torch.zeros(64, 4, 4, dtype=torch.float64)
+    twist[:, 0, 1], twist[:, 0, 2], twist[:, 1, 0] = -w[:, 2], w[:, 1], w[:, 2]
+    twist[:, 1, 2], twist[:, 2, 0], twist[:, 2, 1] = -w[:, 0], -w[:, 1], w[:, 0]
+    twist[:, :3, 3] = v
+    assert (torch.linalg.matrix_exp(twist * theta[:, :, None]) - T).abs().max() < 1e-10
+
+
+def test_encoder_contract():
+    from splatfields_amd.deform_field import SplatFields
+    with pytest.raises(NotImplementedError, match="tri-plane"):
+        SplatFields(n_frames=0)                                  # the default encoder_type asks for the tri-plane encoder
+
+    class Planes(torch.nn.Module):                               # anything with the encoder's interface can be plugged in
+        out_dim = 6
+
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.randn(6, 3))
+
+        def forward(self, x):
+            return x @ self.table.t()
+
+    net = SplatFields(n_frames=4, encoder=Planes(), composition_rank=2)
+    names = set(net.state_dict())
+    assert "encoder.table" in names and "mlp_refine_feat.0.weight" in names and "mlp_flow_head.branch_w.weight" in names
+    assert net.mlp_deform.d_in == 3 * 13 + 6 + 7 and net.mlp_opacity.d_in == 3 * 7 + 6 + 7
+    assert "mlp_deform.net.2.weights_t" in names and "mlp_deform.net.1.weights_t" not in names and "mlp_deform.net.7.weights_t" not in names
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_fused_network_matches_the_reference_network(hip_device, name):
+    run_case(name, hip_device, 5e-5, 5e-4)
