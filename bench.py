@@ -207,6 +207,21 @@ def valu_roofline(workload: dict, stage_ms: dict):
     return out
 
 
+def deform_network_probe():
+    """configs[4] (4-D scene): the SplatFields-shaped deform network at 100 k splats, PyTorch-ROCm vs the fused MLP kernels, next
+    to the rasterizer for the same splats -- tools/deform_net_probe.py in its own process (not part of the timed steps)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "deform_net_probe.py"), "--steps", "10"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    keep = ["splats", "image", "dtype", "net_fwd_bwd_ms", "net_fwd_bwd_fused_mlps_ms", "rasterizer_fwd_bwd_ms", "full_step_ms",
+            "full_step_fused_mlps_ms", "net_forward_ms", "net_forward_fused_mlps_ms", "net_share_of_step", "fused_forward_max_rel_diff",
+            "fused_training_max_rel_grad_diff_parameters", "fused_training_xyz_grad_median_rel_diff"]
+    res = {k: d[k] for k in keep if k in d}
+    res["name"] = "4-D config: deform network (stand-in of the reference's shapes), PyTorch-ROCm vs fused MLP kernels"
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -426,6 +441,12 @@ def main():
             r["name"] = name
             out["other_workloads"].append(r)
             progress(f"workload '{name}' done")
+    if rank == 0 and world == 1 and args.extra_workloads != "none":
+        try:
+            out["deform_network"] = deform_network_probe()
+        except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline line
+            out["deform_network"] = {"error": repr(e)[:300]}
+        progress("deform network probe done")
     if rank == 0 and world == 1 and args.cpu_baseline != "none":
         from oracle.cpu_baseline import run_cpu_baseline, run_torch_oracle_config0  # the oracle: only the timed CPU baseline
         out["cpu_baseline_torch_config0"] = run_torch_oracle_config0()
