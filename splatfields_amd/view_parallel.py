@@ -353,3 +353,50 @@ def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss:
             p.grad = v
         local = views[-1].reshape(())
     return local
+
+
+def field_view_parallel_step(compute_splats: Callable[[], dict], views: Sequence, render_loss: Callable, *, rank: int = None,
+                             world: int = None, group=None) -> torch.Tensor:
+    """Data-parallel step of the NEURAL path (reference train.py:62-101: the splat attributes of an iteration are the output of
+    the deform network -- `means3D`, `scales`, `rotations`, `opacity`, `rgb` -- and every view of the iteration renders them).
+
+    The network is replicated and evaluated once per rank (same points, same time -> the same attributes everywhere); rank r
+    renders views r, r+G, ... of them; what crosses the wire is the gradient with respect to the ATTRIBUTES, 56 B/splat with
+    precomputed colours, in one packed sum all-reduce -- not the network's parameters (5 M floats for
+    the SplatFields shapes) and not one collective per parameter tensor.  Each rank then back-propagates the reduced attribute
+    gradient through its replica, which leaves identical parameter / position gradients on every rank, equal to those of the
+    single-process loop over all views.
+
+    ``compute_splats() -> dict`` runs the network (tensors that require grad take part; other entries pass through);
+    ``render_loss(splats, view) -> scalar`` renders one view from the given attribute tensors.  Gradients accumulate into the
+    ``.grad`` of whatever leaves ``compute_splats`` used (the caller zeroes them, as with a plain backward).  Returns the mean
+    loss over all views."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    outputs = compute_splats()
+    keys = [k for k, v in outputs.items() if torch.is_tensor(v) and v.requires_grad]
+    # detached copies are the "parameters" of the rendering part of the step
+    splats = dict(outputs)
+    for k in keys:
+        splats[k] = outputs[k].detach().requires_grad_(True)
+    mine = shard_views(views, rank, world)
+    total = None
+    for v in mine:
+        l = render_loss(splats, v)
+        total = l if total is None else total + l
+    n_views = len(views)
+    ref = outputs[keys[0]]
+    if total is not None:
+        (total / n_views).backward()
+        local = (total / n_views).detach().to(ref.dtype)
+    else:
+        local = torch.zeros((), device=ref.device, dtype=ref.dtype)
+    grads = [splats[k].grad if splats[k].grad is not None else torch.zeros_like(splats[k]) for k in keys]
+    if _exchange(world):
+        flat, views_ = pack_gradients([g.to(ref.dtype) for g in grads] + [local.reshape(1)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        grads, local = views_[:-1], views_[-1].reshape(())
+    torch.autograd.backward([outputs[k] for k in keys], [g.to(outputs[k].dtype) for k, g in zip(keys, grads)])
+    return local

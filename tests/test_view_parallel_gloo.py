@@ -9,7 +9,7 @@ import torch.multiprocessing as mp
 
 from oracle import torch_oracle as O
 from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-from splatfields_amd.view_parallel import allreduce_gradients, shard_views, view_parallel_step
+from splatfields_amd.view_parallel import allreduce_gradients, field_view_parallel_step, shard_views, view_parallel_step
 
 N, W, H, VIEWS = 120, 40, 32, 3
 
@@ -139,3 +139,81 @@ def test_allreduce_gradients_with_missing_grads_and_active_sh_bands():
         assert torch.equal(torch.from_numpy(o), torch.full((6, 1), 2.0))          # (4 + 0) / 2
         s = torch.from_numpy(s)
         assert torch.equal(s[:, :4], torch.full((6, 4, 3), 15.0)) and (s[:, 4:] == 0).all()
+
+
+# ---- neural path: the splat attributes are the output of a (replicated) network; only attribute gradients are exchanged ----
+
+def build_field():
+    """a small stand-in network (positions, time) -> attributes, and the oracle rasterizer on precomputed colours"""
+    g = torch.Generator().manual_seed(3)
+    sp = make_splats(N, seed=8, mean_scale=0.1, dtype=torch.float64)
+    xyz = sp["means3D"].clone().requires_grad_(True)
+    w1 = (0.3 * torch.randn(3, 16, generator=g, dtype=torch.float64)).requires_grad_(True)
+    w2 = (0.3 * torch.randn(16, 14, generator=g, dtype=torch.float64)).requires_grad_(True)
+    leaves = [xyz, w1, w2]
+    gi, _, _ = make_upstream_grads(H, W, dtype=torch.float64)
+
+    def compute_splats():
+        h = torch.tanh(xyz @ w1) @ w2
+        return {"means3D": xyz + 0.05 * h[:, 0:3], "scales": sp["scales"] * torch.exp(0.1 * h[:, 3:6]),
+                "rotations": torch.nn.functional.normalize(sp["rotations"] + 0.1 * h[:, 6:10], dim=-1),
+                "opacity": torch.sigmoid(h[:, 10:11]), "rgb": torch.sigmoid(h[:, 11:14]), "frame": 3}
+
+    def render_loss(s, view):
+        cam = make_camera(view, W, H)
+        st = O.settings_from_camera(cam, torch.ones(3, dtype=torch.float64), 0)
+        out = O.rasterize(s["means3D"], None, s["opacity"], colors_precomp=s["rgb"], scales=s["scales"], rotations=s["rotations"], settings=st)
+        return (out.color * gi).sum() * 1e3 + ((out.alpha - 0.5) ** 2).mean()
+
+    return leaves, compute_splats, render_loss
+
+
+def field_reference_step():
+    leaves, compute_splats, render_loss = build_field()
+    s = compute_splats()
+    loss = sum(render_loss(s, v) for v in range(VIEWS)) / VIEWS
+    loss.backward()
+    return loss.detach(), [p.grad.clone() for p in leaves]
+
+
+def field_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    leaves, compute_splats, render_loss = build_field()
+    loss = field_view_parallel_step(compute_splats, list(range(VIEWS)), render_loss)
+    q.put((rank, loss.numpy().copy(), [p.grad.numpy().copy() for p in leaves]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_neural_step_equals_single_process_step():
+    """configs[4]'s N > 1 leg: views sharded, network replicated, one packed all-reduce of the attribute gradients, then the
+    network backward on every rank: network and position gradients equal the single-process loop and each other."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=field_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref_loss, ref_grads = field_reference_step()
+    results = sorted((r, torch.from_numpy(l), [torch.from_numpy(g) for g in gs]) for r, l, gs in results)
+    for rank, loss, grads in results:
+        assert torch.allclose(loss, ref_loss, rtol=1e-12, atol=1e-14), rank
+        for g, r in zip(grads, ref_grads):
+            assert torch.allclose(g, r, rtol=1e-9, atol=1e-15), rank
+    for a, b in zip(results[0][2], results[1][2]):
+        assert torch.equal(a, b)
+
+
+def test_neural_step_without_a_process_group_is_the_plain_step():
+    leaves, compute_splats, render_loss = build_field()
+    loss = field_view_parallel_step(compute_splats, list(range(VIEWS)), render_loss, rank=0, world=1)
+    ref_loss, ref_grads = field_reference_step()
+    assert torch.allclose(loss, ref_loss, rtol=1e-12)
+    for p, r in zip(leaves, ref_grads):
+        assert torch.allclose(p.grad, r, rtol=1e-10, atol=1e-16)
