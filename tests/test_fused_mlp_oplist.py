@@ -129,3 +129,25 @@ def test_argument_validation_happens_before_any_launch(monkeypatch):
     b = [torch.zeros(64), torch.zeros(64), torch.zeros(3)]
     with pytest.raises(RuntimeError, match="no CPU path"):
         fm.fused_general_mlp(torch.zeros(5, 20), w, b)
+
+
+def test_packed_layout_is_the_documented_index_formula():
+    """pack_layer_weight (the PyTorch statement the device packer is tested against) element by element against the layout
+    csrc/mlp.hip documents: float ((((c MT + mt) 2 + tl) 64 + 16 k + m) 4 + i) = W'[16 mt + m][16 (2 c + tl) + 4 k + i]."""
+    from splatfields_amd.fused_mlp import pack_layer_weight
+    g = torch.Generator().manual_seed(2)
+    M, n_mem, n_reg, mem_pad, reg_width, MT = 40, 21, 50, 32, 64, 3
+    W = torch.randn(M, n_mem + n_reg, generator=g)
+    packed = pack_layer_weight(W, n_mem, mem_pad, reg_width, MT)
+    Wp = torch.zeros(16 * MT, mem_pad + reg_width)
+    Wp[:M, :n_mem] = W[:, :n_mem]
+    Wp[:M, mem_pad:mem_pad + n_reg] = W[:, n_mem:]
+    assert packed.numel() == 16 * MT * (mem_pad + reg_width)
+    for c in range((mem_pad + reg_width) // 32):
+        for mt in range(MT):
+            for tl in range(2):
+                for lane in range(64):
+                    k, m = lane >> 4, lane & 15
+                    for i in range(4):
+                        d = ((((c * MT + mt) * 2 + tl) * 64 + lane) * 4 + i)
+                        assert packed[d] == Wp[16 * mt + m][16 * (2 * c + tl) + 4 * k + i]
