@@ -1,5 +1,5 @@
-// Fused MLP chains of the SplatFields deform network for gfx950: forward, and the
-// activation-gradient chain of the backward.
+// Fused MLP kernels of the SplatFields deform network for gfx950: the layer chain (forward, and the
+// activation-gradient chain of the backward), the weight packer, and the weight-gradient kernel.
 //
 // What it replaces: reference utils/time_utils.py:123-191 (`GeneralMLP`: Linear -> activation for every layer, the
 // input concatenated back in front of the hidden state after the `skips` layers), which PyTorch-ROCm runs as one GEMM +
@@ -19,7 +19,7 @@
 //   backward, hidden  acc = W_h^T dZ;        dZ <- acc * leaky'(saved activation of the layer below);  stored for dW = dZ^T X
 //   backward, input   acc = W_x^T dZ;        added to dL/dx0 in memory, the register state is kept
 // so the same code walks the network in both directions (the backward's matrices are the transposed blocks, packed the same
-// way); the weight gradients are library GEMMs over the stored dZ and activations (splatfields_amd/fused_mlp.py).
+// way); the weight gradients are a second kernel over the stored dZ and activations (k_mlp_weight_grad below).
 //
 // Packed matrix with MT output tiles and KT input tiles (host side: splatfields_amd/fused_mlp.py):
 //   float index ((((c * MT + mt) * 2 + tl) * 64 + lane) * 4 + i)  =  A[16 mt + (lane & 15)][16 (2 c + tl) + 4 (lane >> 4) + i]
