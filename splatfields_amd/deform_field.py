@@ -170,3 +170,53 @@ class SplatFields(nn.Module):
             flow, means3D = None, xyz_can
         out.update({"flow": flow, "means3D": means3D})
         return out
+
+
+def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0, lr_delay_mult: float = 1.0, max_steps: int = 1000000) -> float:
+    """the reference's schedule (utils/general_utils.py:86-119): log-linear from lr_init to lr_final over max_steps, optionally
+    eased in by lr_delay_mult + (1 - lr_delay_mult) sin(pi/2 clip(step / lr_delay_steps)); 0 for step < 0 or when both rates are 0."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    delay = 1.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1.0 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return delay * math.exp(math.log(lr_init) * (1.0 - t) + math.log(lr_final) * t)
+
+
+class SplatFieldsModel:
+    """Counterpart of reference scene/deform_model.py:9-54 around `SplatFields`: `step(xyz, time_emb)`, Adam over all network
+    parameters at 5 x the position learning rate with the exponential schedule, `deform/iteration_<n>/deform.pth` checkpoints."""
+
+    def __init__(self, hyper_args, radius=None, encoder: Optional[nn.Module] = None, device="cuda"):
+        kwargs = dict(hyper_args.__dict__) if hasattr(hyper_args, "__dict__") else dict(hyper_args)
+        self.deform = SplatFields(radius=radius, encoder=encoder, **kwargs).to(device)
+        self.optimizer = None
+        self.spatial_lr_scale = 5
+
+    def step(self, xyz, time_emb):
+        return self.deform(xyz, time_emb)
+
+    def train_setting(self, training_args):
+        lr0 = training_args.position_lr_init * self.spatial_lr_scale
+        self.optimizer = torch.optim.Adam([{"params": list(self.deform.parameters()), "lr": lr0, "name": "deform"}], lr=0.0, eps=1e-15)
+        self._schedule = dict(lr_init=lr0, lr_final=training_args.position_lr_final, lr_delay_mult=training_args.position_lr_delay_mult,
+                              max_steps=training_args.deform_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "deform":
+                group["lr"] = expon_lr(iteration, **self._schedule)
+                return group["lr"]
+
+    def save_weights(self, model_path, iteration):
+        import os
+        out = os.path.join(model_path, "deform/iteration_{}".format(iteration))
+        os.makedirs(out, exist_ok=True)
+        torch.save(self.deform.state_dict(), os.path.join(out, "deform.pth"))
+
+    def load_weights(self, model_path, iteration=-1):
+        import os
+        if iteration == -1:
+            iteration = max(int(name.split("_")[-1]) for name in os.listdir(os.path.join(model_path, "deform")))
+        self.deform.load_state_dict(torch.load(os.path.join(model_path, "deform/iteration_{}/deform.pth".format(iteration))))

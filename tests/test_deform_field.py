@@ -165,3 +165,47 @@ def test_network_into_rasterizer_one_backward(hip_device, monkeypatch):
     for k in ga_:
         num, den = (ga_[k] - gb_[k]).norm().item(), gb_[k].norm().item()
         assert num <= 1e-2 * den + 1e-12, (k, num, den)      # wiring test; precision is pinned by the fixture tests above
+
+
+def test_learning_rate_schedule_known_values():
+    """values of the reference's get_expon_lr_func (utils/general_utils.py:86-119), evaluated by importing it in the build container"""
+    from splatfields_amd.deform_field import expon_lr
+    a = dict(lr_init=0.00016 * 5, lr_final=0.0000016, lr_delay_mult=0.01, max_steps=40000)
+    want_a = {0: 0.0008000000000000003, 1: 0.0007998757174928709, 1000: 0.0006848819757262796, 20000: 3.577708763999665e-05,
+              40000: 1.5999999999999995e-06, 50000: 1.5999999999999995e-06, -1: 0.0}
+    for step, want in want_a.items():
+        assert expon_lr(step, **a) == pytest.approx(want, rel=1e-12, abs=0)
+    b = dict(lr_init=0.01, lr_final=0.0001, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=3000)
+    want_b = {0: 0.0010000000000000005, 100: 0.0032430793766233938, 500: 0.004641588833612781, 1500: 0.0010000000000000002,
+              3000: 0.00010000000000000009}
+    for step, want in want_b.items():
+        assert expon_lr(step, **b) == pytest.approx(want, rel=1e-12)
+    assert expon_lr(10, 0.0, 0.0) == 0.0
+
+
+def test_model_wrapper_optimizer_schedule_and_checkpoints(tmp_path):
+    """SplatFieldsModel on CPU tensors (no forward): Adam group as the reference builds it, schedule applied to the group,
+    deform/iteration_<n>/deform.pth layout, load of the latest iteration."""
+    import types
+    from splatfields_amd.deform_field import SplatFieldsModel
+    hyper = types.SimpleNamespace(encoder_type="none", composition_rank=1, deform_d=2, rgb_d=2, flow_d=2, scale_d=2, opacity_d=2,
+                                  rotation_d=2, deform_skips=[0], rgb_skips=[0], flow_skips=[0], n_frames=3)
+    kwargs = dict(hyper.__dict__)
+    n_frames = kwargs.pop("n_frames")
+    model = SplatFieldsModel(types.SimpleNamespace(n_frames=n_frames, **kwargs), radius=None, device="cpu")
+    train = types.SimpleNamespace(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, deform_lr_max_steps=40000)
+    model.train_setting(train)
+    group = model.optimizer.param_groups[0]
+    assert group["name"] == "deform" and group["eps"] == 1e-15 and len(group["params"]) == len(list(model.deform.parameters()))
+    assert model.update_learning_rate(1000) == pytest.approx(0.0006848819757262796, rel=1e-12) and group["lr"] == model.update_learning_rate(1000)
+    model.save_weights(str(tmp_path), 7)
+    with torch.no_grad():
+        first = next(model.deform.parameters())
+        saved = first.clone()
+        first.add_(1.0)
+    model.save_weights(str(tmp_path), 12)
+    assert (tmp_path / "deform" / "iteration_7" / "deform.pth").exists()
+    model.load_weights(str(tmp_path), 7)
+    assert torch.equal(next(model.deform.parameters()), saved)
+    model.load_weights(str(tmp_path))                               # latest = 12
+    assert torch.equal(next(model.deform.parameters()), saved + 1.0)
