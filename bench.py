@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md:35 (6.29e12 measured-achievable)
+FP32_PEAK = 157.3e12  # FLOP/s, vector fp32 (same guide, :40)
+SIMDS = 1024          # 256 CUs x 4 SIMD-32
+VALU_ISSUE_CYCLES = 2.0   # a wave64 VALU instruction occupies its SIMD-32 for two cycles (same guide, "Wave scheduling")
+FLOP_PER_PAIR = {"render_forward": 30.0, "render_backward": 90.0}   # SURVEY.md Appendix C, per blended (pixel, splat) pair
 
 
 def parse():
@@ -177,33 +181,72 @@ def blend_work_counters(n, width, height, mean_scale):
                     "last contributor; counted on one fwd+bwd of view 1 by the -DSR_BWD_STATS build (tools/bwd_stats.py)"}
 
 
-def valu_roofline(workload: dict, stage_ms: dict):
-    """Issue-side roofline of the two blend kernels from the committed SQ counter passes (profiles/pmc_sq.json, rocprofv3
-    --pmc, per-launch averages): wave-level VALU / SALU / LDS / MFMA instruction counts and the kernel cycles per wave-VALU
-    instruction per SIMD (kernel cycles = SQ_BUSY_CYCLES / 32 shader engines).  `frac` relates that to the densest issue rate
-    measured in this pipeline (3.7 cycles per instruction per SIMD: the forward blend and round 1's backward blend, whose
-    VALU pipes are saturated).  The counters are a recorded measurement of this workload; the launch duration next to them
-    is the live one."""
-    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return 0.0 if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+def recorded_counters(name: str, workload: dict, check_hash: bool = True):
+    """A counter file under profiles/ (rocprofv3 --pmc passes condensed by tools/summarize_profile.py) if it was recorded for
+    this workload AND for the kernel sources the library is built from (`_source_hash`); otherwise (None, reason)."""
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None
+        return None, "no recorded counters"
     try:
         pj = json.load(open(path))
     except Exception:
-        return None
-    if pj.get("_workload") != workload:
-        return None
-    out = {"source": pj.get("_source"), "simds": 1024, "issue_bound_cycles_per_valu_inst_per_simd": 3.7}
+        return None, "unreadable counter file"
+    want = {k: workload[k] for k in pj.get("_workload", {}) if k in workload}
+    if pj.get("_workload") != want or not want:
+        return None, "counters were recorded for another workload"
+    if check_hash:
+        from splatfields_amd.build import source_hash
+        if pj.get("_source_hash") != source_hash():
+            return None, "kernel sources changed since the counters were recorded (tools/profile.sh + tools/summarize_profile.py)"
+    return pj, None
+
+
+def valu_roofline(workload: dict, stage_ms: dict, pairs_blended=None, check_hash: bool = True):
+    """Issue-side view of the two blend kernels (they are VALU-bound, not HBM-bound), against HARDWARE ceilings:
+
+    * `valu_issue_frac` = wave-level VALU instructions x 2 cycles / 1024 SIMDs / kernel cycles: the share of the launch during
+      which a SIMD's VALU port is at least occupied (every wave64 VALU instruction takes two cycles of its SIMD-32; DPP,
+      v_cmp / v_cndmask and transcendental instructions take more, so 1.0 is not reachable with this instruction mix).
+      Kernel cycles = SQ_BUSY_CYCLES / 32 shader engines, i.e. counted at the clock the launch really ran at
+      (`clock_ghz` = cycles / duration of the traced launch), not at the 2.4 GHz maximum.
+    * `useful_flop_frac` = blended (pixel, splat) pairs x FLOP per pair (30 forward / 90 backward)
+      / live launch duration / 157.3 TFLOP/s: what the fp32 vector peak would need for the work that reaches the image.
+    * `wave_cycle_shares`: where the resident wavefronts spend their cycles -- parked (s_waitcnt / barrier: SQ_WAIT_ANY),
+      issue-stalled (SQ_WAIT_INST_ANY), issuing (SQ_ACTIVE_INST_ANY) over SQ_WAVE_CYCLES.
+
+    The counters are a recorded rocprofv3 measurement of this workload and these kernel sources (profiles/pmc_sq.json); the
+    launch duration next to them is the live one."""
+    pj, why = recorded_counters("pmc_sq.json", workload, check_hash)
+    if pj is None:
+        return None if why in ("no recorded counters", "counters were recorded for another workload") else {"stale": why}
+    out = {"source": pj.get("_source"), "source_hash": pj.get("_source_hash"), "simds": SIMDS,
+           "valu_issue_cycles_per_wave_inst": VALU_ISSUE_CYCLES, "fp32_peak_tflops": FP32_PEAK / 1e12}
     for stage in ("render_forward", "render_backward"):
         c = pj.get(stage)
         if not c:
             continue
         cycles = c["SQ_BUSY_CYCLES"] / 32.0            # summed over the 32 shader engines
-        out[stage] = {"wave_valu_insts_per_launch": c["SQ_INSTS_VALU"], "wave_salu_insts_per_launch": c["SQ_INSTS_SALU"],
-                      "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "mfma_insts_per_launch": c.get("SQ_INSTS_MFMA"),
-                      "kernel_cycles": cycles, "cycles_per_valu_inst_per_simd": cycles * 1024.0 / c["SQ_INSTS_VALU"],
-                      "frac": min(1.0, 3.7 / (cycles * 1024.0 / c["SQ_INSTS_VALU"])),
-                      "live_avg_launch_ms": stage_ms.get(stage)}
+        st = {"wave_valu_insts_per_launch": c["SQ_INSTS_VALU"], "wave_salu_insts_per_launch": c["SQ_INSTS_SALU"],
+              "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "mfma_insts_per_launch": c.get("SQ_INSTS_MFMA"),
+              "kernel_cycles": cycles, "cycles_per_valu_inst_per_simd": cycles * SIMDS / c["SQ_INSTS_VALU"],
+              "valu_issue_frac": c["SQ_INSTS_VALU"] * VALU_ISSUE_CYCLES / SIMDS / cycles,
+              "live_avg_launch_ms": stage_ms.get(stage)}
+        st["frac"] = st["valu_issue_frac"]
+        if c.get("avg_launch_ns_kernel_trace"):
+            st["clock_ghz"] = cycles / c["avg_launch_ns_kernel_trace"]
+        wc = c.get("SQ_WAVE_CYCLES")
+        if wc:
+            st["wave_cycle_shares"] = {"parked": c.get("SQ_WAIT_ANY", 0.0) / wc, "issue_stalled": c.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                                       "issuing": c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc}
+        if pairs_blended and stage_ms.get(stage):
+            st["useful_flop_frac"] = pairs_blended * FLOP_PER_PAIR[stage] / (stage_ms[stage] * 1e-3) / FP32_PEAK
+        out[stage] = st
     return out
 
 
@@ -347,25 +390,42 @@ def main():
             break
         state["mode"] = modes[modes.index(state["mode"]) + 1]
     t_start = time.perf_counter()
+    from splatfields_amd.view_parallel import ExchangeStats
     for i in range(args.warmup):
         one_step(i)
     fence()
+    # Timed region (task contract): exactly K steps between barrier + synchronize on both sides, max over ranks -> `value`.
+    # Inside it every step is also bracketed by HIP events on the launch stream; `ms_per_step` is the MEDIAN of those
+    # per-step times (robust against the odd slow step; box-to-box variance is +-3 %), the wall-clock mean is
+    # reported beside it.  Recording an event costs the stream nothing measurable.
+    ExchangeStats.reset(world > 1 or args.force_dp_path)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    stream = torch.cuda.current_stream(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
+        marks[i].record(stream)
         one_step(args.warmup + i)
+        ExchangeStats.end_step()
+    marks[args.steps].record(stream)
     fence()
     t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    med = torch.tensor([median(step_ms)], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(med, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_wall = elapsed / args.steps * 1e3
+    ms_per_step = float(med.item())
     value = world * N * H * W * args.steps / elapsed
+    exchange = ExchangeStats.summary() if ExchangeStats.enabled else None
+    ExchangeStats.reset(False)
 
     def progress(msg):
         if rank == 0:
             print(f"[bench] {msg} (+{time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
 
-    progress(f"timed {args.steps} steps: {ms_per_step:.4f} ms/step")
+    progress(f"timed {args.steps} steps: median {ms_per_step:.4f} ms/step, wall-clock mean {ms_wall:.4f}")
     # ---- per-stage durations with HIP events on the launch stream (same steps, same inputs) ----
     lib.sr_profile_enable(1)
     for i in range(args.steps):
@@ -382,19 +442,17 @@ def main():
     dom_bytes = stage_bytes(dom, N, vis, R, H * W, c_in)
     dom_bw = dom_bytes / (stage_ms[dom] * 1e-3)
     b_alg = pipeline_bytes(N, vis, R, H * W, c_in)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            same = tj.get("_workload") == {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree}
-            traffic = tj.get(dom) if same else None  # PMC bytes were collected for that workload only
-        except Exception:
-            traffic = None
+    wl = {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree, "mean_scale": args.mean_scale}
+    tj, traffic_why = recorded_counters("traffic.json", wl)   # PMC bytes of this workload and these kernel sources only
+    traffic = tj.get(dom) if tj else None
 
     out = {
         "metric": "splats*px rasterized/sec (fwd+bwd)", "value": value, "unit": "splat*px/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_wall_mean": ms_wall,
+        "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms),
+        "timing": "value = work / wall-clock of the K timed steps (barrier + synchronize on both sides, max over ranks); ms_per_step = "
+                  "median over the K per-step HIP-event times (max over ranks), ms_per_step_wall_mean = that wall-clock / K",
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
                                f"1 view per GPU per step, colour+depth+alpha outputs, fwd+bwd"
@@ -405,7 +463,8 @@ def main():
                    "splats": N, "width": W, "height": H, "views_per_step": world,
                    "visible_splats": vis, "tile_instances": R, "inputs": args.inputs, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": dom_bw / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
+                     "frac": dom_bw / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_why,
+                     "algorithmic_bytes_per_launch": dom_bytes,
                      "avg_launch_ms": stage_ms[dom],
                      "note": ("the two blend kernels are VALU-issue-bound, not HBM-bound (rocprofv3 SQ counters in profiles/: 4.6-4.9 "
                               "launch cycles per wave-level VALU instruction per SIMD); `traffic` is L2<->fabric bytes incl. requests "
@@ -413,23 +472,40 @@ def main():
                               "(DESIGN.md section 5)")},
         "roofline_pipeline": {"b_alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                               "frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
+                              "frac_from_wall_mean": b_alg / (ms_wall * 1e-3) / HBM_PEAK,
                               "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
         "stage_ms": stage_ms,
         # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
         "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }
     progress("stage pass done")
-    wl = {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree, "mean_scale": args.mean_scale}
-    out["roofline_valu"] = valu_roofline(wl, stage_ms)
     out["roofline"]["note"] = ("the blend kernels are VALU-issue-bound, not HBM-bound: see roofline_valu (SQ counters) and blend_work "
                                "(pairs evaluated / blended); `traffic` is L2<->fabric bytes incl. requests served by the 256 MB "
                                "infinity cache; the HBM-bound stages are preprocess / preprocess_backward (DESIGN.md section 5)")
+    pairs_blended = None
     if rank == 0 and world == 1 and args.extra_workloads != "none":
         try:
             out["blend_work"] = blend_work_counters(N, W, H, args.mean_scale)
+            pairs_blended = out["blend_work"]["pairs_blended"]
         except Exception as e:  # noqa: BLE001 -- a missing counting build must not cost the headline line
             out["blend_work"] = {"error": repr(e)}
         progress("blend_work done")
+    out["roofline_valu"] = valu_roofline(wl, stage_ms, pairs_blended)
+    if world > 1 or args.force_dp_path:
+        # what a first run on a multi-GPU node needs to be diagnosed: which scheme ran over how many RCCL ranks, how long the
+        # exchange window of a step is, how much of it is covered by local compute, what every GPU puts on the wire
+        ex = exchange or {}
+        out["exchange"] = {
+            "dp_mode": state["mode"], "backend": args.backend if world > 1 else None,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "exchange_ms": ex.get("exchange_ms"), "overlap_ms": ex.get("overlap_ms"),
+            "compute_ms": (ms_per_step - ex["exchange_ms"] + ex["overlap_ms"]) if ex else None,
+            "exposed_exchange_ms": (ex["exchange_ms"] - ex["overlap_ms"]) if ex else None,
+            "wire_bytes_per_gpu": ex.get("wire_bytes_per_gpu"),
+            "wire_bytes_per_splat_per_gpu": (ex["wire_bytes_per_gpu"] / N) if ex else None,
+            "note": "rank 0's medians over the timed steps; exchange_ms = first collective issued -> last one complete (events on the "
+                    "launch stream), overlap_ms = local compute inside that window (the SH-gradient rebuild), wire bytes by the ring "
+                    "model (all-reduce 2 (G-1)/G S, all-gather / all-to-all (G-1)/G S)"}
     if rank == 0 and world == 1 and args.extra_workloads != "none":
         # SURVEY.md 8d "both colour paths" + denser tile lists (trained scenes sit at 5-15 instances per splat)
         extra = [("headline, precomputed colours", N, W, H, False, args.mean_scale),

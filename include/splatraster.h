@@ -157,6 +157,12 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
                 const SrGrads* grads, void* hip_stream);
 
+/* Pins the backward blend kernel for A/B measurements and for the test that compares the two: 0 = chosen per launch by the
+ * footprint (default), 1 = pixel-per-lane kernel, 2 = entry-per-lane kernel.  The initial value comes from the environment
+ * variable SPLATRASTER_BWD ("wave" = 1, "mfma" = 2), read once when the library is loaded.  Process-wide; returns the
+ * previous setting, or -1 for an unknown value (nothing changes). */
+int sr_set_backward_kernel(int which);
+
 /* present[i] = 1 iff splat i passes the near-plane test (view z > 0.2). */
 int sr_mark_visible(int n_splats, const float* means3D, const float* viewmatrix,
                     const float* projmatrix, unsigned char* present, void* hip_stream);

@@ -30,6 +30,17 @@ def is_stale() -> bool:
     return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and headers the library is built from: recorded counter files under
+    profiles/ carry it, and bench.py refuses them when the sources have changed since they were collected."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        h.update((CSRC / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False, out: Path = None, defines=()) -> Path:
     """hipcc --offload-arch=gfx950 ... -> splatfields_amd/libsplatraster.so (cross-compiles without a GPU).
 

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -44,7 +45,7 @@ struct StageTimer {
 // Pinned word + event per (host thread, device) for the asynchronous instance-count read-back of sr_forward
 // (the only state the library keeps besides the profiling counters; created lazily, a few bytes each).  Thread-local, so
 // host threads that drive different streams of one device do not share the read-back word.
-struct HostSync { uint32_t* pinned = nullptr; hipEvent_t ev = nullptr; };
+struct HostSync { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
 thread_local HostSync g_sync[64];
 
 int get_host_sync(HostSync** out) {
@@ -52,12 +53,23 @@ int get_host_sync(HostSync** out) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail("hipGetDevice failed");
     HostSync& h = g_sync[dev];
     if (!h.pinned) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+        // coherent (fine-grained) host memory: k_scan_small stores the two counters straight into it
+        if (hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocCoherent) != hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h.pinned, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
+        h.pinned_dev = static_cast<uint32_t*>(dp);
         if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     }
     *out = &h;
     return 0;
 }
+
+// 0 = choose the backward blend kernel by footprint, 1 = pixel-per-lane, 2 = entry-per-lane (sr_set_backward_kernel)
+std::atomic<int> g_bwd_kernel{[] {
+    const char* sel = getenv("SPLATRASTER_BWD");
+    return !sel ? 0 : (std::string(sel) == "wave" ? 1 : (std::string(sel) == "mfma" ? 2 : 0));
+}()};
 
 #define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
@@ -122,20 +134,21 @@ const char* sr_last_error(void) { return g_last_error.c_str(); }
 size_t sr_geom_bytes(int n, int h, int w) { return sr::carve_geom(nullptr, n, h, w, nullptr); }
 size_t sr_binning_bytes(long long r, int, int) { return sr::carve_binning(nullptr, r, nullptr); }
 size_t sr_image_bytes(int h, int w) { return sr::carve_image(nullptr, h, w, nullptr); }
-// scratch layout: [reached: 1 byte per instance][slots: 48 bytes per instance]
+// scratch layout: one 48-byte gradient slot per tile-splat instance (written only for the instances the forward reached)
 size_t sr_backward_scratch_bytes(long long r) {
     const size_t n = (size_t)(r > 0 ? r : 1);
-    return sr::align_up(n, 256) + sr::align_up(n * sr::kSlotFloats * sizeof(float), 256);
+    return sr::align_up(n * sr::kSlotFloats * sizeof(float), 256);
 }
 
 }  // extern "C"
 
 namespace {
 
-int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, int* radii, hipStream_t st) {
+int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, int* radii, uint32_t* host_out,
+                  hipStream_t st) {
     { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
     SR_TRY(after_launch(view, st, "preprocess"));
-    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, st); }
+    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, host_out, st); }
     SR_TRY(after_launch(view, st, "scan"));
     return 0;
 }
@@ -174,10 +187,9 @@ int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, i
     const sr::SplatsK s = make_splats(splats);
     sr::Geom g;
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
-    SR_TRY(launch_stage1(view, v, s, g, radii, st));
     HostSync* hs = nullptr;
     SR_TRY(get_host_sync(&hs));
-    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));
     SR_TRY(check_hip(hipStreamSynchronize(st), "sync after prepare"));
     *instances_out = (long long)hs->pinned[0];
     return 0;
@@ -198,8 +210,7 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
     sr::carve_image(image, v.H, v.W, &im);
     HostSync* hs = nullptr;
     SR_TRY(get_host_sync(&hs));
-    SR_TRY(launch_stage1(view, v, s, g, radii, st));
-    SR_TRY(check_hip(hipMemcpyAsync(hs->pinned, g.total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read instance count"));
+    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));   // k_scan_small stores the two counters into hs->pinned
     SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
     SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, st));  // waits inside, GPU busy
     const long long total = (long long)hs->pinned[0];
@@ -243,21 +254,18 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     sr::carve_geom(const_cast<void*>(geom), s.N, v.H, v.W, &g);
     sr::carve_binning(const_cast<void*>(binning), instances, &b);
     sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
-    const size_t n_inst = (size_t)(instances > 0 ? instances : 1);
-    uint8_t* reached = static_cast<uint8_t*>(scratch);
-    float* slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + sr::align_up(n_inst, 256));
-    SR_TRY(check_hip(hipMemsetAsync(reached, 0, n_inst, st), "clear reached flags"));
+    float* slots = static_cast<float*>(scratch);
     {
         StageTimer t_(5, st);
         // Two kernels, one slot format.  Entry-per-lane (MFMA moment reduction) wins while a splat reaches few pixels of a tile
         // (measured on MI355X, 800x800: 0.286 vs 0.370 ms at 2.3 instances per splat, 0.207 vs 0.215 at 4.6); pixel-per-lane
         // (wave butterflies) wins once most lanes of an 8x8 sub-tile are inside the footprint (0.192 vs 0.203 at 7.4, 0.182 vs
         // 0.203 at 15).  SPLATRASTER_BWD=wave|mfma pins one of them (A/B measurements).
-        const char* sel = getenv("SPLATRASTER_BWD");
+        const int pinned = g_bwd_kernel.load(std::memory_order_relaxed);   // sr_set_backward_kernel / SPLATRASTER_BWD at load time
         const bool dense = instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N;
-        const bool wave_kernel = sel ? std::string(sel) == "wave" : dense;
-        if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
-        else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached, st);
+        const bool wave_kernel = pinned ? pinned == 1 : dense;
+        if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
+        else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
     }
     SR_TRY(after_launch(view, st, "render_backward"));
     sr::GradsK gr;
@@ -267,9 +275,14 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     gr.shs = s.shs ? grads->dL_dshs : nullptr;
     gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
     gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
-    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, reached, gr, st); }
+    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, st); }
     SR_TRY(after_launch(view, st, "preprocess_backward"));
     return 0;
+}
+
+int sr_set_backward_kernel(int which) {
+    if (which < 0 || which > 2) return -1;
+    return g_bwd_kernel.exchange(which, std::memory_order_relaxed);
 }
 
 int sr_mark_visible(int n, const float* means3D, const float* viewmatrix, const float*, unsigned char* present, void* hip_stream) {

@@ -105,7 +105,8 @@ void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
 // block 1: per-tile totals (count-matrix path: sum of the segment totals, also producing the exclusive
 //          prefix over segments; fallback path: the atomically accumulated tile_count) -> tile_start[tiles+1];
 //          clears tile_cursor
-__global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, int n_tiles, const Chunking ch, int use_matrix) {
+__global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, int n_tiles, const Chunking ch, int use_matrix,
+                                                      uint32_t* __restrict__ host_out) {
     __shared__ uint32_t s_wave[16];
     const bool tiles = blockIdx.x == 1;
     uint32_t* dst = tiles ? g.tile_start : g.block_offsets;
@@ -146,14 +147,16 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         carry += all;
         __syncthreads();
     }
-    if (tid == 0) { if (tiles) dst[n] = carry; else { g.total[0] = carry; g.total[2] = 0u; } }
+    // host_out: two words of pinned host memory (sr_forward's instance count / longest list read-back): stored from here,
+    // the host reads them after the event that follows this kernel -- no copy command in the stream
+    if (tid == 0) { if (tiles) dst[n] = carry; else { g.total[0] = carry; if (host_out) host_out[0] = carry; } }
     if (tiles) {  // longest tile list: lets the host skip the launches of the rare long-list sort classes
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
         __syncthreads();
         if (lane == 0) s_wave[w] = vmax;
         __syncthreads();
-        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; s_wave[0] = m; }
+        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; s_wave[0] = m; if (host_out) host_out[1] = m; }
         __syncthreads();
         // Launch order of the blend kernels: longest lists first (longest-processing-time-first keeps the tail of the
         // launch short: 2500 tiles are only ~1.6 rounds of resident workgroups).  Counting sort into 256 linear length
@@ -183,10 +186,10 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
     }
 }
 
-void launch_scan_small(const ViewK& v, int N, const Geom& g, hipStream_t st) {
+void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, hipStream_t st) {
     const Chunking ch = make_chunking(N, v.gx * v.gy);
     hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, st, g, (N + kBlock - 1) / kBlock, v.gx * v.gy, ch,
-                       use_count_matrix(v) ? 1 : 0);
+                       use_count_matrix(v) ? 1 : 0, host_out);
 }
 
 // ---- emit instances straight into their tile's segment -------------------------------------
@@ -204,9 +207,21 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     if (g.total[0] > b.capacity) return;  // binning buffer too small: the host re-runs stage 2 with a larger one
     int sb0 = blockIdx.x, sb1 = blockIdx.x + 1;
     if constexpr (MATRIX) {
-        sb0 = blockIdx.x * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
-        const uint32_t* row = g.cnt + (size_t)blockIdx.x * ch.tiles_padded;
-        const uint32_t* sbase = g.segbase + (size_t)(blockIdx.x / kSegRows) * ch.tiles_padded;
+        // Which chunk this workgroup scatters.  Inside a tile's segment of `ent` the chunks' pieces (~1 entry each at 1 M
+        // splats) follow each other in chunk order, and workgroup b runs on XCD b % 8 with its own L2: dealt round-robin,
+        // every 128-byte line of the segment would collect 8-byte pieces from all eight L2s and leave each of them as a
+        // masked partial write (measured: 2.97x the algorithmic bytes).  Giving every XCD a contiguous band of chunks lets one
+        // L2 assemble whole lines.
+#ifndef SR_EMIT_NO_XCD_BANDS
+        const int per = (ch.chunks + 7) >> 3;
+        const int chunk = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= per || chunk >= ch.chunks) return;
+#else
+        const int chunk = (int)blockIdx.x;
+#endif
+        sb0 = chunk * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+        const uint32_t* row = g.cnt + (size_t)chunk * ch.tiles_padded;
+        const uint32_t* sbase = g.segbase + (size_t)(chunk / kSegRows) * ch.tiles_padded;
         const int n_tiles = v.gx * v.gy;
         for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + sbase[t] + row[t];
     }
@@ -230,7 +245,8 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         const uint32_t first_splat = (uint32_t)sb * kBlock;
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t) {
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst) {
+            b.reached[base + local_inst] = 0;   // instance order: consecutive threads, consecutive bytes
             uint32_t slot;
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
@@ -244,7 +260,7 @@ void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStre
     const Chunking ch = make_chunking(N, v.gx * v.gy);
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_emit<true>), 1, (int)(sizeof(uint32_t) * kMaxMatrixTiles));   // see launch_count_tiles
     if (use_count_matrix(v))
-        hipLaunchKernelGGL(k_emit<true>, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, b, ch);
+        hipLaunchKernelGGL(k_emit<true>, dim3((ch.chunks + 7) / 8 * 8), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, b, ch);
     else
         hipLaunchKernelGGL(k_emit<false>, dim3(ch.n_sub), dim3(kBlock), 0, st, v, N, g, b, ch);
 }

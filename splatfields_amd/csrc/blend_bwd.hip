@@ -19,13 +19,11 @@
 //     = two v_mfma_f32_16x16x4_f32 per step (exact fp32 fma chains), accumulated over the four steps: no butterflies,
 //     no products with dx, dy in the VALU stream.  Moments are taken about the TILE centre and shifted to the splat
 //     centre once per (tile, entry) when the quads' partial sums are combined.
-//   * the quads' entry lists are built per chunk of the tile list from an exact-support test (quadmask.h), bucketed
-//     with ballots + prefix counts; a slot of the LDS scratch first carries the entry's record to the wavefront that
+//   * the quads' entry lists are built per chunk of the tile list from the quad-reach masks the forward left per list entry
+//     (exact-support test, quadmask.h), bucketed with ballots + prefix counts; a slot of the LDS scratch first carries the entry's record to the wavefront that
 //     owns the quad and then carries the 10 sums back.  Everything is summed in a fixed order: bit-reproducible,
 //     no floating-point atomics (as before).
 #include "kernels.h"
-#define SR_QM_DEVICE 1
-#include "quadmask.h"
 
 namespace sr {
 
@@ -34,13 +32,18 @@ namespace {
 constexpr int kBucket = 16;                 // list entries per bucket = N of the MFMA
 constexpr int kBlkEntries = 32;             // granularity of a chunk of the tile list ("block" = half a wavefront's entries)
 constexpr int kBlocks = 8;                  // a chunk = up to 8 blocks = one list entry per thread
+// (quad, entry) slots per chunk; one block can need 32 x 16 = 512.  A slot holds 10 floats (12 when the caller supplies a
+// depth gradient, so that the record's depth rides along): 880 slots x 40 B + 10 KB of tables = 45 KB of LDS, three
+// workgroups per CU.  (768 slots = 40 KB = four per CU with the registers capped at 128 was measured and is slower,
+// 0.290 vs 0.277 ms: the kernel is issue-bound, a fourth workgroup adds spills and chunks, not throughput.)
 #ifndef SR_BWD_CAP
 #define SR_BWD_CAP 880
 #endif
-// (quad, entry) slots per chunk; one block can need 32 x 16 = 512.  880 slots x 48 B + 11 KB of tables = 53 KB of LDS:
-// three workgroups per CU (160 KB)
 constexpr int kCap = SR_BWD_CAP;
 static_assert(kCap >= kBlkEntries * 16 && kCap % 16 == 0, "one block must always fit");
+#ifndef SR_BWD_WAVES_PER_SIMD
+#define SR_BWD_WAVES_PER_SIMD 3   // register budget: 512 / 3 = 168 per lane
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -160,6 +163,80 @@ __device__ __forceinline__ BwdEntry load_entry(const Geom& g, int pos, uint32_t 
     return e;
 }
 
+// ---- the LDS slot of one (quad, entry) pair -------------------------------------------------------------------------
+// It first carries the entry's record to the wavefront that replays the quad, then the ten sums back to the entry's thread:
+//   in : [0] cx  [1] cy  [2] list position (int bits)  [3] p | [4] s  [5] q  [6] -log2 o  [7] r | [8] g  [9] b | ([10] depth)
+//   out: [0..3] M0 MX MY MXX | [4..7] MXY MYY dr dg | [8] db  [9] d(depth)
+// 10 floats (8-byte aligned, moved as 64-bit pieces) unless the depth gradient is live: then 12 floats, 128-bit pieces.
+template <bool HAS_D> struct SlotFmt { static constexpr int kF = HAS_D ? 12 : 10; };
+
+struct SlotIn { float cx, cy, p, s, q, nlo, r, g, b, depth; int pos; };
+
+template <bool HAS_D>
+__device__ __forceinline__ void slot_put_record(float* sl, const BwdEntry& e) {
+    if constexpr (HAS_D) {
+        float4* d = reinterpret_cast<float4*>(sl);
+        d[0] = make_float4(e.r0.x, e.r0.y, __int_as_float(e.pos), e.r1.x);
+        d[1] = make_float4(e.r1.y, e.r1.z, e.r1.w, e.r2.x);
+        d[2] = make_float4(e.r2.y, e.r2.z, e.r2.w, 0.f);
+    } else {
+        float2* d = reinterpret_cast<float2*>(sl);
+        d[0] = make_float2(e.r0.x, e.r0.y);
+        d[1] = make_float2(__int_as_float(e.pos), e.r1.x);
+        d[2] = make_float2(e.r1.y, e.r1.z);
+        d[3] = make_float2(e.r1.w, e.r2.x);
+        d[4] = make_float2(e.r2.y, e.r2.z);
+    }
+}
+template <bool HAS_D>
+__device__ __forceinline__ SlotIn slot_get_record(const float* sl) {
+    SlotIn r;
+    if constexpr (HAS_D) {
+        const float4* d = reinterpret_cast<const float4*>(sl);
+        const float4 a = d[0], b = d[1], c = d[2];
+        r.cx = a.x; r.cy = a.y; r.pos = __float_as_int(a.z); r.p = a.w;
+        r.s = b.x; r.q = b.y; r.nlo = b.z; r.r = b.w;
+        r.g = c.x; r.b = c.y; r.depth = c.z;
+    } else {
+        const float2* d = reinterpret_cast<const float2*>(sl);
+        const float2 a = d[0], b = d[1], c = d[2], e = d[3], f = d[4];
+        r.cx = a.x; r.cy = a.y; r.pos = __float_as_int(b.x); r.p = b.y;
+        r.s = c.x; r.q = c.y; r.nlo = e.x; r.r = e.y;
+        r.g = f.x; r.b = f.y; r.depth = 0.f;
+    }
+    return r;
+}
+// a lane without an entry: alpha = 0 (only the exponent offset decides; the rest of the stale slot is kept finite)
+__device__ __forceinline__ void slot_mask_invalid(SlotIn& r, bool valid) {
+    r.nlo = valid ? r.nlo : __builtin_inff();
+    r.pos = valid ? r.pos : 0x7fffffff;
+    r.cx = valid ? r.cx : 0.f; r.cy = valid ? r.cy : 0.f;
+    r.p = valid ? r.p : 0.f; r.s = valid ? r.s : 0.f; r.q = valid ? r.q : 0.f;
+    r.r = valid ? r.r : 0.f; r.g = valid ? r.g : 0.f; r.b = valid ? r.b : 0.f; r.depth = valid ? r.depth : 0.f;
+}
+// rows 4 k .. 4 k + 3 of the 16 x 16 result (k = lane >> 4 < 3) -> floats [4 k, 4 k + 3] of the slot
+template <bool HAS_D>
+__device__ __forceinline__ void slot_put_sums(float* sl, int k, const f32x4 d) {
+    if constexpr (HAS_D) {
+        reinterpret_cast<float4*>(sl)[k] = make_float4(d[0], d[1], d[2], d[3]);
+    } else {
+        float2* o = reinterpret_cast<float2*>(sl) + 2 * k;
+        o[0] = make_float2(d[0], d[1]);
+        if (k < 2) o[1] = make_float2(d[2], d[3]);
+    }
+}
+template <bool HAS_D>
+__device__ __forceinline__ void slot_get_sums(const float* sl, float4& a, float4& b, float2& c) {
+    if constexpr (HAS_D) {
+        const float4* d = reinterpret_cast<const float4*>(sl);
+        a = d[0]; b = d[1]; const float4 t = d[2]; c = make_float2(t.x, t.y);
+    } else {
+        const float2* d = reinterpret_cast<const float2*>(sl);
+        const float2 x0 = d[0], x1 = d[1], x2 = d[2], x3 = d[3];
+        a = make_float4(x0.x, x0.y, x1.x, x1.y); b = make_float4(x2.x, x2.y, x3.x, x3.y); c = d[4];
+    }
+}
+
 // Per-quad constants of the replay (pixel row k of the quad, pixel columns t = 0..3).
 struct QuadCtx {
     float pxf[4], gR[4], gG[4], gB[4], gD[4], gA[4], A1[4], A2[4];
@@ -170,15 +247,15 @@ struct QuadCtx {
 // One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
 // the "colour behind . g" of every pixel from bucket to bucket: an UP bucket (entries back to front in lanes 0..15) takes
 // them from lane 0 and leaves them in lane 15, a DOWN bucket (entries in lanes 15..0) the other way round.
-template <bool UP>
-__device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0, const float4 e1, const float4 e2, const int pos,
-                                              float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
-    const float dy = e0.y - c.pyf;
+template <bool UP, bool HAS_D>
+__device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e, float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
+    const float dy = e.cy - c.pyf;
+    const float4 f = make_float4(e.p, e.s, e.q, e.nlo);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const float dx = e0.x - c.pxf[t];
-        const float oG = pair_alpha_unclamped(dx, dy, e1);   // opacity * G: the forward's instruction sequence
-        const bool hit = (oG >= kAlphaMin) && (pos < c.last[t]);
+        const float dx = e.cx - c.pxf[t];
+        const float oG = pair_alpha_unclamped(dx, dy, f);   // opacity * G: the forward's instruction sequence
+        const bool hit = (oG >= kAlphaMin) && (e.pos < c.last[t]);
         const float oGc = hit ? oG : 0.0f;                   // everyone else: alpha = G = 0, transparent to the scans
 #ifdef SR_BWD_STATS
         { const int nh = __popcll(__builtin_amdgcn_ballot_w64(hit)); if (lane == 0) SR_STAT_ADD(4, nh); }
@@ -190,7 +267,8 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0,
         ST[t] = T;   // last lane of the scan: behind the next bucket
         const float wgt = alpha * T;
         float cgv = c.gA[t];   // the alpha channel's "colour" is 1 for every splat
-        cgv = fmaf(e2.w, c.gD[t], cgv); cgv = fmaf(e2.z, c.gB[t], cgv); cgv = fmaf(e2.y, c.gG[t], cgv); cgv = fmaf(e2.x, c.gR[t], cgv);
+        if (HAS_D) cgv = fmaf(e.depth, c.gD[t], cgv);
+        cgv = fmaf(e.b, c.gB[t], cgv); cgv = fmaf(e.g, c.gG[t], cgv); cgv = fmaf(e.r, c.gR[t], cgv);
         const float z = wgt * cgv;
         // (colour accumulated behind entry n, incl. background) . upstream gradient
         const float behind = row_scan_add<UP>(shift_in_carry<UP>(SB[t], z));
@@ -204,14 +282,14 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const float4 e0,
     (void)lane;
 }
 
-__global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im,
-                                                                 const float* __restrict__ dL_dcolor,
-                                                                 const float* __restrict__ dL_ddepth,
-                                                                 const float* __restrict__ dL_dalpha,
-                                                                 float* __restrict__ slots, uint8_t* __restrict__ reached) {
-    // slot i: [3 i] = (cx, cy, list position, -) -> (M0, MX, MY, MXX); [3 i + 1] = (p, s, q, -log2 o) -> (MXY, MYY, dr, dg);
-    //         [3 i + 2] = (r, g, b, depth) -> (db, dd, 0, 0)
-    __shared__ float4 s_slot[kCap * 3];
+// HAS_D: the caller supplied dL/ddepth.  SplatFields' default losses leave the depth gradient empty (reference
+// arguments/__init__.py:166,168): the depth channel is then compiled out of the replay and of the LDS slots.
+template <bool HAS_D>
+__global__ void __launch_bounds__(kBlock, HAS_D ? 3 : SR_BWD_WAVES_PER_SIMD)   // with the depth channel the 48-byte slots allow three per CU anyway
+k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im, const float* __restrict__ dL_dcolor,
+                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha, float* __restrict__ slots) {
+    constexpr int kF = SlotFmt<HAS_D>::kF;
+    __shared__ __attribute__((aligned(16))) float s_slot[kCap * kF];
     __shared__ float4 s_pixA[256];                   // per pixel of the tile: dL/d(r, g, b, depth)
     __shared__ float4 s_pixB[256];                   // (dL/dalpha, last contributor + 1 [int bits], T state, "behind . g" state)
     // the small tables are double-buffered by chunk parity: a wavefront may start testing the next chunk while others
@@ -219,14 +297,12 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
     __shared__ uint32_t s_mask[2][16][kBlocks];      // [quad][block]: entries of the block that reach the quad
     __shared__ uint16_t s_bb[2][16][kBlocks];        // slot of the first entry of (quad, block)
     __shared__ uint32_t s_qlen[2][16], s_qbase[2][16];
-    __shared__ uint32_t s_qlast[16];
     __shared__ uint32_t s_ticket[2];                 // next quad to replay in this chunk (wavefronts take quads as they get free)
 
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = wave_id(), lane = lane_id();
-    const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
-    const int n = (int)(end - start);
+    const uint32_t start = g.tile_start[tile];
     const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
 #ifdef SR_BWD_STATS
     long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_ = clock64();
@@ -234,7 +310,32 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
 
     const int tid = (int)threadIdx.x;
     const uint32_t* ids = b.sorted_id + start;
-    const bool flags = use_reached_flags(g.total);
+    const uint16_t* qms = b.qmask + start;
+
+    // How far the forward got, per 4x4 quad (Geom::tile_qlast, written at the end of the forward blend): list entries at
+    // positions >= qlast[q] are behind the stop of every pixel of quad q.  The tile is uniform, so these are scalar loads;
+    // nothing of the per-pixel data is needed to start fetching the list.
+    uint32_t qlast[16];
+    {
+        const uint32_t* ql = g.tile_qlast + 16 * (size_t)tile;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) qlast[q] = ql[q];
+    }
+    uint32_t bmax_u = 0u, qlast_min = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { bmax_u = max(bmax_u, qlast[q]); qlast_min = min(qlast_min, qlast[q]); }
+    const int bmax = __builtin_amdgcn_readfirstlane((int)bmax_u);   // uniform by construction; tell the compiler
+    qlast_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlast_min);
+
+    // first chunk's entries: requested before anything else
+    int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
+    BwdEntry cur;
+    uint32_t cur_qm;
+    {
+        const int pos = hi - 1 - tid;
+        cur_qm = pos >= 0 ? (uint32_t)qms[pos] : 0u;
+        cur = load_entry(g, pos, pos >= 0 ? ids[pos] : 0u);
+    }
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -248,60 +349,36 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
             my_last = im.n_contrib[pix];
             T_final = im.final_T[pix];
             gR = dL_dcolor[pix]; gG = dL_dcolor[hw + pix]; gB = dL_dcolor[2 * hw + pix];
-            if (dL_ddepth) gD = dL_ddepth[pix];
+            if (HAS_D) gD = dL_ddepth[pix];
             if (dL_dalpha) gA = dL_dalpha[pix];
         }
         const float bg_dot = v.bg[0] * gR + v.bg[1] * gG + v.bg[2] * gB;
         s_pixA[threadIdx.x] = make_float4(gR, gG, gB, gD);
         s_pixB[threadIdx.x] = make_float4(gA, __uint_as_float(my_last), T_final, T_final * bg_dot);
-        if (threadIdx.x < 16) s_qlast[threadIdx.x] = 0u;
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
-        __syncthreads();
-        atomicMax(&s_qlast[(ly >> 2) * 4 + (lx >> 2)], my_last);   // LDS, integer: order-independent
-        __syncthreads();
+        // no barrier here: the first readers of these tables (replay) sit behind the two barriers of the first chunk
     }
-    uint32_t bmax_u = 0u, qlast_min = 0xffffffffu;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const uint32_t x = s_qlast[q]; bmax_u = max(bmax_u, x); qlast_min = min(qlast_min, x); }
-    const int bmax = __builtin_amdgcn_readfirstlane((int)bmax_u);   // uniform by construction; tell the compiler
-    qlast_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlast_min);
 
     const int k = lane >> 4, nl = lane & 15;
     const uint32_t lt_mask = (1u << (lane & 31)) - 1u;   // earlier entries of this thread's block
     const int myblk = (int)threadIdx.x >> 5;
 
-    // first chunk's entries: requested before anything else of the loop needs them
-    int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
-    BwdEntry cur;
-    {
-        const int pos = hi - 1 - tid;
-        cur = load_entry(g, pos, pos >= 0 ? ids[pos] : 0u);
-    }
-
     float4* slot4 = reinterpret_cast<float4*>(slots);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // List entries behind every pixel's last contributor receive no gradient.  With `flags` their slots are not written
-    // at all and their `reached` byte stays 0 (the buffer is cleared before the launch); otherwise they are zero-filled.
-    if (!flags) {
-        for (int i = bmax + tid; i < n; i += kBlock) {
-            const uint32_t id = ids[i];
-            const ushort4 rc = g.rect[id];
-            const size_t inst = g.offsets[id] + (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
-            slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
-        }
-    }
+    // List entries at positions >= bmax (behind every pixel's stop) receive no gradient and no slot: their `reached` byte
+    // stays 0 (cleared by the scatter) and k_preprocess_backward skips them.
 
     int par = 0;   // chunk parity: which copy of the small tables
     SR_PHASE(0);   // preamble
     while (hi > 0) {
-        // ---------------- (A) test: which quads does this thread's entry reach? ----------------
+        // ---------------- (A) which quads does this thread's entry reach?  (mask from the forward, minus finished quads) ----
         uint32_t qm = 0u, inst = 0u;
         if (cur.pos >= 0) {
             inst = cur.first + ((uint32_t)ty - (cur.rect_xy >> 16)) * cur.rect_w + ((uint32_t)tx - (cur.rect_xy & 0xffffu));
-            qm = sr_quad_mask(cur.r0.x, cur.r0.y, cur.r0.z, cur.r1.x, cur.r1.y, cur.r1.z, tx0f, ty0f);
+            qm = cur_qm;
             if ((uint32_t)cur.pos >= qlast_min) {   // behind the last contributor of every pixel of some quad
 #pragma unroll
-                for (int q = 0; q < 16; ++q) if ((uint32_t)cur.pos >= s_qlast[q]) qm &= ~(1u << q);
+                for (int q = 0; q < 16; ++q) if ((uint32_t)cur.pos >= qlast[q]) qm &= ~(1u << q);
             }
         }
         {   // one ballot per quad (its halves are the wavefront's two blocks); lane q (< 16) collects quad q's mask
@@ -354,6 +431,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
         // latencies hide behind the replay
         const int npos = hi - kBlkEntries * used - 1 - tid;
         const uint32_t nid = npos >= 0 ? ids[npos] : 0u;
+        const uint32_t nqm = npos >= 0 ? (uint32_t)qms[npos] : 0u;
         // ---------------- (C) scatter the records into the quads' slot runs ----------------
         if (myblk < used) {
             uint32_t m = qm;
@@ -361,9 +439,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
                 const int q = __builtin_ctz(m);
                 m &= m - 1u;
                 const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
-                s_slot[3 * slot] = make_float4(cur.r0.x, cur.r0.y, __int_as_float(cur.pos), 0.f);
-                s_slot[3 * slot + 1] = cur.r1;
-                s_slot[3 * slot + 2] = cur.r2;
+                slot_put_record<HAS_D>(s_slot + kF * slot, cur);
             }
         }
         const BwdEntry nxt = load_entry(g, npos, nid);
@@ -408,50 +484,42 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
             // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
             // interleave.  The slots of the next iteration are read while this one computes.
             const int last_bucket = ((len - 1) >> 4) << 4;   // first entry of the quad's last bucket
-            auto slot_of = [&](int i, bool up) { return base + min(i, last_bucket) + (up ? nl : 15 - nl); };
+            auto slot_of = [&](int i, bool up) { return s_slot + kF * (base + min(i, last_bucket) + (up ? nl : 15 - nl)); };
             int i0 = 0;
-            int sa = slot_of(0, true), sb = slot_of(kBucket, false);
-            float4 a0 = s_slot[3 * sa], a1 = s_slot[3 * sa + 1], a2 = s_slot[3 * sa + 2];
-            float4 b0 = s_slot[3 * sb], b1 = s_slot[3 * sb + 1], b2 = s_slot[3 * sb + 2];
+            float* sa = slot_of(0, true);
+            float* sb = slot_of(kBucket, false);
+            SlotIn ea = slot_get_record<HAS_D>(sa), eb = slot_get_record<HAS_D>(sb);
 #pragma unroll 1
             for (; i0 + kBucket < len; i0 += 2 * kBucket) {
-                const int sa_n = slot_of(i0 + 2 * kBucket, true), sb_n = slot_of(i0 + 3 * kBucket, false);
-                const float4 na0 = s_slot[3 * sa_n], na1 = s_slot[3 * sa_n + 1], na2 = s_slot[3 * sa_n + 2];
-                const float4 nb0 = s_slot[3 * sb_n], nb1 = s_slot[3 * sb_n + 1], nb2 = s_slot[3 * sb_n + 2];
+                float* sa_n = slot_of(i0 + 2 * kBucket, true);
+                float* sb_n = slot_of(i0 + 3 * kBucket, false);
+                const SlotIn na = slot_get_record<HAS_D>(sa_n), nb = slot_get_record<HAS_D>(sb_n);
                 const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
-                const int pa = __float_as_int(a0.z), pb = vb ? __float_as_int(b0.z) : 0x7fffffff;
-                b1.w = vb ? b1.w : __builtin_inff();   // a lane without an entry: alpha = 0 (only the exponent offset decides;
-                b0.x = vb ? b0.x : 0.f; b0.y = vb ? b0.y : 0.f;   // the rest of the stale slot is kept finite)
-                b1.x = vb ? b1.x : 0.f; b1.y = vb ? b1.y : 0.f; b1.z = vb ? b1.z : 0.f;
-                b2.x = vb ? b2.x : 0.f; b2.y = vb ? b2.y : 0.f; b2.z = vb ? b2.z : 0.f; b2.w = vb ? b2.w : 0.f;
+                slot_mask_invalid(eb, vb);
                 f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
 #ifdef SR_BWD_STATS
                 if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
 #endif
-                replay_bucket<true>(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
-                replay_bucket<false>(c, b0, b1, b2, pb, ST, SB, D1b, D2b, lane);
+                replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
+                replay_bucket<false, HAS_D>(c, eb, ST, SB, D1b, D2b, lane);
                 // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
                 if (k < 3) {
-                    s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
-                    if (vb) s_slot[3 * sb + k] = make_float4(D1b[0] + D2b[0], D1b[1] + D2b[1], D1b[2] + D2b[2], D1b[3] + D2b[3]);
+                    slot_put_sums<HAS_D>(sa, k, D1a + D2a);
+                    if (vb) slot_put_sums<HAS_D>(sb, k, D1b + D2b);
                 }
                 sa = sa_n; sb = sb_n;
-                a0 = na0; a1 = na1; a2 = na2; b0 = nb0; b1 = nb1; b2 = nb2;
+                ea = na; eb = nb;
             }
             const bool tail = i0 < len;   // a last single bucket (UP): its carries end in lane 15, otherwise they are in lane 0
             if (tail) {
                 const bool va = i0 + nl < len;
-                const int pa = va ? __float_as_int(a0.z) : 0x7fffffff;
-                a1.w = va ? a1.w : __builtin_inff();
-                a0.x = va ? a0.x : 0.f; a0.y = va ? a0.y : 0.f;
-                a1.x = va ? a1.x : 0.f; a1.y = va ? a1.y : 0.f; a1.z = va ? a1.z : 0.f;
-                a2.x = va ? a2.x : 0.f; a2.y = va ? a2.y : 0.f; a2.z = va ? a2.z : 0.f; a2.w = va ? a2.w : 0.f;
+                slot_mask_invalid(ea, va);
                 f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a;
 #ifdef SR_BWD_STATS
                 if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
 #endif
-                replay_bucket<true>(c, a0, a1, a2, pa, ST, SB, D1a, D2a, lane);
-                if (k < 3 && va) s_slot[3 * sa + k] = make_float4(D1a[0] + D2a[0], D1a[1] + D2a[1], D1a[2] + D2a[2], D1a[3] + D2a[3]);
+                replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
+                if (k < 3 && va) slot_put_sums<HAS_D>(sa, k, D1a + D2a);
             }
             if (nl == (tail ? 15 : 0)) {
 #pragma unroll
@@ -466,16 +534,18 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
         SR_PHASE(6);   // barrier after (D)
         // ---------------- (E) combine the quads' sums of every entry, shift the moments to the splat centre ----------------
         if (myblk < used && cur.pos >= 0) {
-            float4 s0 = zero4, s1 = zero4, s2 = zero4;
+            float4 s0 = zero4, s1 = zero4;
+            float2 s2 = make_float2(0.f, 0.f);
             uint32_t m = qm;
             while (m) {   // ascending quad index: fixed summation order
                 const int q = __builtin_ctz(m);
                 m &= m - 1u;
                 const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
-                const float4 a = s_slot[3 * slot], cc = s_slot[3 * slot + 1], d = s_slot[3 * slot + 2];
+                float4 a, cc; float2 d;
+                slot_get_sums<HAS_D>(s_slot + kF * slot, a, cc, d);
                 s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
                 s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
-                s2.x += d.x; s2.y += d.y;
+                s2.x += d.x; if (HAS_D) s2.y += d.y;
             }
             // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
             const float ox = cur.r0.x - (tx0f + 7.5f), oy = cur.r0.y - (ty0f + 7.5f);
@@ -487,12 +557,13 @@ __global__ void __launch_bounds__(kBlock) k_render_backward_mfma(const ViewK v, 
             slot4[(size_t)inst * 3] = make_float4(M0, Sx, Sy, Sxx);
             slot4[(size_t)inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
             slot4[(size_t)inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
-            if (flags) reached[inst] = 1;
+            b.reached[inst] = 1;
         }
         // no barrier here: the next chunk's (A) touches only the other copy of the small tables, and its scatter (C) comes
         // after the barrier that follows (A)
         hi -= kBlkEntries * used;
         cur = nxt;
+        cur_qm = nqm;
         par ^= 1;
         SR_PHASE(7);   // (E) combine
     }
@@ -519,10 +590,11 @@ int backward_stats(unsigned long long* out8, int reset) {   // out8: 16 entries
 
 void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                                 float* slots, uint8_t* reached, hipStream_t st) {
+                                 float* slots, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    hipLaunchKernelGGL(k_render_backward_mfma, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
+    if (dL_ddepth) hipLaunchKernelGGL(k_render_backward_mfma<true>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else hipLaunchKernelGGL(k_render_backward_mfma<false>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
 }
 
 }  // namespace sr

@@ -53,7 +53,10 @@ struct Geom {
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
     uint32_t* tile_order;    // [tiles] tiles by decreasing list length (coarse classes): launch order of the blend kernels
-    uint32_t* total;         // [0] number of instances, [1] longest tile list, [2] sum over tiles of the entries the forward reached
+    uint32_t* total;         // [0] number of instances, [1] longest tile list
+    // written by the forward blend, read by the backward kernels:
+    uint32_t* tile_qlast;    // [tiles][16] per 4x4-pixel quad (row-major in the tile): list entries in front of the stop of its
+                             //     last pixel (max over the quad's pixels of n_contrib); the backward replays [0, max over quads)
     // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
     uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
     uint32_t* segtot;        // [segments][tiles_padded] column totals per segment of kSegRows chunks
@@ -89,6 +92,14 @@ struct Binning {
     uint64_t* keys_tmp;  // [R] ping-pong buffer B
     uint32_t* sorted_id; // [R] splat index, per tile front-to-back.  The instance index (slot of the backward scratch) is
                          //     not stored: offsets[splat] + row-major position of the tile inside the splat's tile rect
+    uint16_t* qmask;     // [R] per list entry (same order as sorted_id): which 4x4-pixel quads of its tile the splat can reach
+                         //     with alpha >= 1/255 (bit 4 qy + qx, quadmask.h).  Computed once by the forward blend while it stages
+                         //     the entry, used there for the sub-tile culling and by the backward blend for its bucketing
+    uint8_t* reached;    // [R] per tile-splat INSTANCE (index = offsets[splat] + position of the tile in the splat's rect): 1 once
+                         //     the backward blend has written its gradient slot.  Cleared by the scatter (k_emit walks the
+                         //     instances in exactly this order: coalesced byte stores, no separate clearing pass), set by the
+                         //     backward blend for the list entries in front of the stop of the tile's last pixel, tested by
+                         //     k_preprocess_backward: unreached slots are neither written nor read
     uint32_t capacity;   // instances the arrays above were carved for; stage-2 kernels exit if total > capacity
 };
 
@@ -126,6 +137,7 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
     t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);
     t.tile_cursor = c.take<uint32_t>(tiles); t.tile_order = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
+    t.tile_qlast = c.take<uint32_t>(16 * tiles);
     t.cnt = t.segtot = t.segbase = nullptr;
     if (tiles <= (size_t)kMaxMatrixTiles) {
         const Chunking ch = make_chunking(N, (int)tiles);
@@ -145,6 +157,8 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     t.keys = c.take<uint64_t>(r);
     t.keys_tmp = c.take<uint64_t>(r);
     t.sorted_id = c.take<uint32_t>(r);
+    t.qmask = c.take<uint16_t>(r);
+    t.reached = c.take<uint8_t>(r);
     t.capacity = (uint32_t)(R > 0 ? R : 0);
     if (b) *b = t;
     return align_up(c.off, 256);
@@ -161,18 +175,10 @@ inline size_t carve_image(void* base, int H, int W, Image* im) {
 
 // One record of the backward scratch: per tile-splat instance, the tile-reduced moment sums.
 // (S0, Sx, Sy, Sxx | Sxy, Syy, dr, dg | db, ddepth, pad, pad)
+// Only the instances the forward reached (list position in front of the stop of the tile's last pixel) are written by the
+// backward blend and read by k_preprocess_backward; Binning::reached says which.
 constexpr int kSlotFloats = 12;
 
-#ifdef __HIPCC__
-// Backward bookkeeping mode, decided on the device from what the forward recorded (same expression in both backward
-// kernels): when early termination left a good part of the tile lists unreached (dense scenes), unreached slots are
-// neither written nor read and a `reached` byte per instance says which are valid; when nearly everything was reached
-// (sparse clouds such as the 1 M headline workload) the few unreached slots are zero-filled instead and the per-splat
-// reduction reads every slot without a dependent flag load.
-__device__ __forceinline__ bool use_reached_flags(const uint32_t* total) {
-    return (float)total[2] < 0.8f * (float)total[0];
-}
-#endif
 
 // ---- per-view constants, passed to kernels by value ----------------------------------------
 struct ViewK {

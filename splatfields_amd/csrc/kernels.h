@@ -28,7 +28,7 @@ void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g,
 // true when the image is small enough for the atomic-free count-matrix bucketing
 inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixTiles; }
 void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st);
-void launch_scan_small(const ViewK& v, int N, const Geom& g, hipStream_t st);
+void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, hipStream_t st);
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st);
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st);
 // render.hip
@@ -36,11 +36,11 @@ void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, cons
                            float* out_color, float* out_depth, float* out_alpha, hipStream_t st);
 void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* slots, uint8_t* reached, hipStream_t st);
+                            float* slots, hipStream_t st);
 // blend_bwd.hip
 void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                                 float* slots, uint8_t* reached, hipStream_t st);
+                                 float* slots, hipStream_t st);
 
 int backward_stats(unsigned long long* out8, int reset);
 

@@ -393,12 +393,12 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }
     float q_norm = 1.0f;
     if (s.raw) activate_inputs(s.raw, sc_in, opac_in, q_in, q_norm);
-    // `reached` bytes of the first 4 instances are requested now, together with the splat's own loads
-    // (most splats have <= 4 instances)
-    const bool flags_on = use_reached_flags(g.total);
-    uint32_t reached4 = 0x01010101u;
-    if (flags_on && valid && radius_in > 0) {
-        reached4 = 0;
+    // Which of the splat's instances hold a gradient slot: the backward blend wrote one (and set the instance's `reached` byte)
+    // for every list entry in front of the stop of its tile's last pixel; the others are neither written nor read.  The bytes
+    // of the first 4 instances are requested now, together with the splat's own loads (most splats have <= 4 instances).
+    const bool vis_in = valid && radius_in > 0;
+    uint32_t reached4 = 0u;
+    if (vis_in) {
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i)
             if (i < cnt_in) reached4 |= (uint32_t)reached[first_in + i] << (8 * i);
@@ -411,7 +411,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     for (int k = 0; k < 10; ++k) sum[k] = 0.f;
     {
         const float4* sl_all = reinterpret_cast<const float4*>(slots);
-        const bool vis_in = valid && radius_in > 0;
         const bool big = vis_in && cnt_in >= 32u;
         const int lane = lane_id();
         uint64_t todo = __ballot(big);
@@ -423,7 +422,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 #pragma unroll
             for (int k = 0; k < 10; ++k) part[k] = 0.f;
             for (uint32_t i = lane; i < c; i += 64u) {
-                if (flags_on && !reached[f + i]) continue;  // never written by the backward blend: contributes nothing
+                if (!reached[f + i]) continue;  // never written by the backward blend: contributes nothing
                 const float4* sl = sl_all + (size_t)(f + i) * 3;
                 const float4 a = sl[0], b4 = sl[1], c4 = sl[2];
                 part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
@@ -439,7 +438,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         if (vis_in && !big) {
             const float4* sl = sl_all + (size_t)first_in * 3;
             for (uint32_t i = 0; i < cnt_in; ++i) {
-                const bool hit = !flags_on || (i < 4u ? ((reached4 >> (8 * i)) & 0xffu) != 0u : reached[first_in + i] != 0);
+                const bool hit = i < 4u ? ((reached4 >> (8 * i)) & 0xffu) != 0u : reached[first_in + i] != 0;
                 if (!hit) continue;
                 const float4 a = sl[3 * i], b4 = sl[3 * i + 1], c4 = sl[3 * i + 2];
                 sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;

@@ -14,10 +14,11 @@
 // reductions, combines the 4 wavefronts through LDS in a fixed order and writes ONE record per
 // tile-splat instance to a scratch slot: no floating-point atomics anywhere, bit-reproducible.
 #include "kernels.h"
+#define SR_QM_DEVICE 1
+#include "quadmask.h"
 
 namespace sr {
 
-constexpr int kFwdBatch = 256;
 constexpr int kBwdBatch = 128;  // 64 / 96 / 192 / 256 all measured slower (tried and rejected)
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -56,25 +57,77 @@ __device__ __forceinline__ float swap16_add(float x, float y) {
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
+// What the backward needs to know about how far the forward got, written once per tile at the end of the forward blend:
+//   tile_qlast[tile][quad] = max over the quad's pixels of `last` (entries in front of the pixel's stop).
+// The backward blend replays entries [0, max over the quads) without first reducing the per-pixel values itself.
+// D1..D4: the four lane-index bits that enumerate the 16 pixels of a quad in the caller's lane layout; `writer`: one lane
+// per quad.
+__device__ __forceinline__ void publish_tile_reach(const Geom& g, int tile, uint32_t last, int qx, int qy, int D1, int D2, int D3, int D4,
+                                                   bool writer) {
+    uint32_t ql = last;
+    ql = max(ql, (uint32_t)__shfl_xor((int)ql, D1, 64));
+    ql = max(ql, (uint32_t)__shfl_xor((int)ql, D2, 64));
+    ql = max(ql, (uint32_t)__shfl_xor((int)ql, D3, 64));
+    ql = max(ql, (uint32_t)__shfl_xor((int)ql, D4, 64));
+    if (writer) g.tile_qlast[16 * (size_t)tile + 4 * qy + qx] = ql;
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
+// Asynchronous 16-byte-per-lane copy memory -> LDS (global_load_lds_dwordx4): lane l's 16 bytes at `src` land at LDS byte
+// address `lds_base` + 16 l, with no register staging and no ds_write.  Written as inline assembly on purpose: hipcc drains
+// every outstanding memory operation at the next barrier / first use when it tracks such a copy itself, whereas these
+// requests are meant to stay in flight across a whole batch of blending; the kernel waits for them with lds_copy_wait().
+// M0 (the LDS base) is reserved by the compiler: saved and restored inside the statement.
+__device__ __forceinline__ void lds_copy16_async(const void* src, uint32_t lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only (this wavefront's LDS operations are complete before it arrives): unlike
+// __syncthreads() it carries no release fence, so requests to global memory stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of the flat address
+
 __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const Geom g, const Binning b, const Image im,
                                                            float* __restrict__ out_color, float* __restrict__ out_depth,
                                                            float* __restrict__ out_alpha) {
-    __shared__ float4 s_r0[kFwdBatch];
-    __shared__ float4 s_r1[kFwdBatch];
-    __shared__ float4 s_r2[kFwdBatch];
+#ifndef SR_FWD_BUFS
+#define SR_FWD_BUFS 1
+#endif
+#ifndef SR_FWD_BATCH
+#define SR_FWD_BATCH 256
+#endif
+    // Staging area of one batch of the tile's list: the three hot quarters of every entry's record and its quad-reach mask.
+    // SR_FWD_BUFS copies of SR_FWD_BATCH entries.  Measured on MI355X (headline workload): 1 x 256 (12.5 KB of LDS, eight
+    // workgroups per CU) 0.115 ms; 2 x 256 with the next batch in flight during the blending (25 KB, six per CU) 0.134 ms
+    // -- the blend loop is issue-bound and lives on its occupancy, the other workgroups of the CU already cover a batch's
+    // gather; the first version (registers -> LDS, per-wave box tests, 12 KB) 0.120 ms.
+    constexpr int kB = SR_FWD_BATCH;
+    static_assert(kB == 256 || kB == 128, "a batch is staged by four or by two wavefronts");
+    constexpr int kStagers = kB / kWave;       // wavefronts that stage one batch
+    constexpr uint32_t kStep = 4 / kStagers;   // a wavefront stages every kStep-th batch
+    __shared__ float4 s_r0[SR_FWD_BUFS][kB];
+    __shared__ float4 s_r1[SR_FWD_BUFS][kB];
+    __shared__ float4 s_r2[SR_FWD_BUFS][kB];
+    __shared__ uint16_t s_qm[SR_FWD_BUFS][kB];   // quad-reach mask of every staged entry (quadmask.h)
+    __shared__ uint32_t s_live[2][4];            // per batch parity and wavefront: does it still have accumulating pixels?
 
     if (g.total[0] > b.capacity) return;  // uniform: see sr_forward
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
-    const int wave = wave_id(), lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
     const bool inside = px < v.W && py < v.H;
-    const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
+    const float sxf = (float)sx, syf = (float)sy; (void)sxf; (void)syf;
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
+    // the four 4x4 quads of this wavefront's 8x8 sub-tile as bits 4 qy + qx
+    const uint32_t my_quads = 0x33u << (2 * (wave & 1) + 8 * (wave >> 1));
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
     // Pixels still accumulating (not yet stopped by T < 1e-4) are tracked as a SCALAR 64-bit mask: all the skip / stop /
@@ -84,35 +137,88 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     // true last contributor fail the alpha test there exactly as they did here, so the looser bound changes no result.
     uint64_t livem = __builtin_amdgcn_ballot_w64(inside);
     uint32_t last = inside ? end - start : 0u;
-
-    for (uint32_t base = start; base < end; base += kFwdBatch) {
-        if (__syncthreads_count(livem != 0ull) == 0) break;  // also fences LDS reuse
-        const uint32_t i = base + threadIdx.x;
+    if (start == end) {   // uniform: nothing to blend (the reach table still has to be written)
+        goto done;
+    }
+    {
+    // Which wavefronts stage batch k: all four (256 entries), or {0, 1} for even k and {2, 3} for odd k (128 entries).
+    auto stages = [&](uint32_t k) { return kStagers == 4 || (uint32_t)(wave >> 1) == (k & 1u); };
+    const int slot = kStagers == 4 ? (int)threadIdx.x : (int)(threadIdx.x & 127u);   // this thread's entry of a batch it stages
+    const int wslot = kStagers == 4 ? wave : (wave & 1);                              // its wavefront's 64-entry group there
+    // LDS byte addresses of this wavefront's 64 slots in each copy (wave-uniform: the copy instruction adds 16 x lane)
+    const uint32_t l0 = lds_address(&s_r0[0][wslot * kWave]), l1 = lds_address(&s_r1[0][wslot * kWave]), l2 = lds_address(&s_r2[0][wslot * kWave]);
+    constexpr uint32_t kCopyStride = kB * sizeof(float4);
+    // request the three record quarters of a list entry (index clamped into the list: threads past its end re-request the
+    // last entry, whose mask below is zero) into copy `buf`: LDS-direct loads, no staging registers, no ds_write
+    auto request = [&](int buf, uint32_t id) {
+        const float4* rec = g.rec + 4 * (size_t)id;
+        lds_copy16_async(rec, l0 + buf * kCopyStride);
+        lds_copy16_async(rec + 1, l1 + buf * kCopyStride);
+        lds_copy16_async(rec + 2, l2 + buf * kCopyStride);
+    };
+    // after the copies of `buf` have landed: this thread's entry -> its quad-reach mask (exact support of alpha >= 1/255
+    // against the sixteen 4x4 quads, quadmask.h): LDS for this kernel's sub-tile culling, memory for the backward's bucketing
+    auto publish_mask = [&](int buf, uint32_t i) {
+        uint32_t qm = 0u;
+#ifndef SR_FWD_NO_QMASK
         if (i < end) {
-            const uint32_t id = b.sorted_id[i];
-            const float4* rec = g.rec + 4 * (size_t)id;
-            s_r0[threadIdx.x] = rec[0];
-            s_r1[threadIdx.x] = rec[1];
-            s_r2[threadIdx.x] = rec[2];
+            const float4 r0 = s_r0[buf][slot], r1 = s_r1[buf][slot];
+            qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
+            b.qmask[i] = (uint16_t)qm;
         }
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)kFwdBatch, end - base);
+#endif
+        s_qm[buf][slot] = (uint16_t)qm;
+    };
+    const uint32_t lastpos = end - 1u;
+    const uint32_t i0 = start + (uint32_t)slot;   // this thread's entry of batch 0
+    // Splat indices are plain loads with the index clamped into the list (unconditional: no branch).  id_nxt = index of this
+    // thread's entry in the NEXT batch it stages; it is (re)loaded right after the thread's copies have landed and before
+    // its next copies go out: while LDS-direct copies are in flight no ordinary load may be pending, because the wait the
+    // compiler places in front of its first use counts (and would drain) the copies as well.
+    const uint32_t k_first = kStagers == 4 ? 1u : ((wave >> 1) == 1 ? 1u : 2u);
+    uint32_t id_nxt = b.sorted_id[min(i0 + k_first * kB, lastpos)];
+    if (stages(0u)) {
+        const uint32_t id0 = b.sorted_id[min(i0, lastpos)];
+        request(0, id0);
+        lds_copy_wait();
+        publish_mask(0, i0);
+    }
+    asm volatile("" :: "v"(id_nxt));
+    lds_barrier();
+
+    uint32_t k = 0;
+    for (uint32_t base = start; base < end; base += kB, ++k) {
+        const bool more = base + kB < end;   // uniform
+        const int buf = SR_FWD_BUFS == 2 ? (int)(k & 1u) : 0;
+        const int nbuf = SR_FWD_BUFS == 2 ? buf ^ 1 : 0;
+        // (The empty statement makes the compiler wait for the index load on EVERY path into the blend loop: it must not
+        // believe a load is still pending there, or it protects the reuse of that register with a wait inside the loop.)
+        asm volatile("" :: "v"(id_nxt));
+#if SR_FWD_BUFS == 2
+        // the other copy is free (every wavefront has passed the barrier behind its batch): start filling it
+        if (more && stages(k + 1u)) request(nbuf, id_nxt);
+#endif
+        const int cnt = (int)min((uint32_t)kB, end - base);
         if (livem != 0ull) {
-            // 64 staged entries at a time: one lane tests one entry against this wavefront's 8x8 pixels, the
-            // ballot is a scalar bit mask, and the wavefront walks its set bits -- uniform control flow, the
-            // LDS address of the next record is known without a dependent index load, the body is branch-free.
+            // 64 staged entries at a time: one lane looks at one entry's quad mask, the ballot is a scalar bit mask, and the
+            // wavefront walks its set bits -- uniform control flow, the LDS address of the next record is known without a
+            // dependent index load, the body is branch-free.
             // (The loop is co-limited by the scalar unit: ~4.3 cycles per SALU instruction per SIMD on MI355X.)
             for (int c = 0; c < cnt; c += kWave) {
                 const int el = c + lane;
+#ifdef SR_FWD_SUBTILE_TEST
                 const int ec = el < cnt ? el : cnt - 1;
-                const bool ok = el < cnt && subtile_overlap(s_r0[ec], s_r1[ec], sxf, syf);
+                const bool ok = el < cnt && subtile_overlap(s_r0[buf][ec], s_r1[buf][ec], sxf, syf);
+#else
+                const bool ok = el < cnt && ((uint32_t)s_qm[buf][el < cnt ? el : 0] & my_quads) != 0u;
+#endif
                 uint64_t m = __builtin_amdgcn_ballot_w64(ok);
                 const uint32_t pos0 = (base - start) + (uint32_t)c;
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
                     m &= ~(1ull << bit);
                     const int e = c + bit;
-                    const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
+                    const float4 r0 = s_r0[buf][e], r1 = s_r1[buf][e], r2 = s_r2[buf][e];
                     const float alpha = fminf(kAlphaMax, pair_alpha_unclamped(r0.x - pxf, r0.y - pyf, r1));
                     const float test_T = T * (1.0f - alpha);
                     const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & livem;
@@ -127,17 +233,25 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                 if (livem == 0ull) break;
             }
         }
+        if (!more) break;
+        if (lane == 0) s_live[k & 1u][wave] = livem != 0ull ? 1u : 0u;
+#if SR_FWD_BUFS == 1
+        lds_barrier();   // everybody is done with the batch: the one copy may be overwritten
+        if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped
+        if (stages(k + 1u)) request(0, id_nxt);
+#endif
+        if (stages(k + 1u)) {
+            lds_copy_wait();
+            id_nxt = b.sorted_id[min(base + (1u + kStep) * kB + (uint32_t)slot, lastpos)];
+            publish_mask(nbuf, base + kB + (uint32_t)slot);
+        }
+        lds_barrier();
+#if SR_FWD_BUFS == 2
+        if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped
+#endif
     }
-    {   // entries of this tile's list the forward reached (max over its pixels): input of use_reached_flags()
-        uint32_t wl = last;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
-        __shared__ uint32_t s_last[4];
-        __syncthreads();
-        if (lane == 0) s_last[wave] = wl;
-        __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(&g.total[2], max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3])));
     }
+done:
     if (inside) {
         const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
         out_color[pix] = Cr + T * v.bg[0];
@@ -148,6 +262,8 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         im.final_T[pix] = T;
         im.n_contrib[pix] = last;
     }
+    publish_tile_reach(g, tile, last, /*quad of this lane: */ 2 * (wave & 1) + ((lane >> 2) & 1), 2 * (wave >> 1) + ((lane >> 5) & 1),
+                       /*lane bits spanning a quad: */ 1, 2, 8, 16, (lane & 0x1b) == 0);
 }
 
 void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
@@ -166,7 +282,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                                                             const float* __restrict__ dL_dcolor,
                                                             const float* __restrict__ dL_ddepth,
                                                             const float* __restrict__ dL_dalpha,
-                                                            float* __restrict__ slots, uint8_t* __restrict__ reached) {
+                                                            float* __restrict__ slots) {
     // slot kBwdBatch is a sentinel record whose exponent offset is +inf (alpha = 0): the dummy entries of an incomplete
     // group of 4 point at it and contribute nothing without any special-casing in the loop
     __shared__ float4 s_r0[kBwdBatch + 1];
@@ -206,17 +322,8 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
     float4* slot4 = reinterpret_cast<float4*>(slots);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // List entries behind every pixel's last contributor receive no gradient.  With `flags` their slots are not written
-    // at all and their `reached` byte stays 0 (the buffer is cleared before the launch); otherwise they are zero-filled.
-    const bool flags = use_reached_flags(g.total);
-    if (!flags) {
-        for (int i = bmax + (int)threadIdx.x; i < n; i += kBlock) {
-            const uint32_t id = b.sorted_id[start + i];
-            const ushort4 rc = g.rect[id];
-            const size_t inst = g.offsets[id] + (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
-            slot4[inst * 3] = zero4; slot4[inst * 3 + 1] = zero4; slot4[inst * 3 + 2] = zero4;
-        }
-    }
+    // List entries at positions >= bmax (behind every pixel's stop) receive no gradient and no slot: their `reached` byte
+    // stays 0 (cleared by the scatter) and k_preprocess_backward skips them.
 
     if (threadIdx.x == 0) {
         s_r0[kBwdBatch] = zero4;
@@ -333,7 +440,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                 slot4[inst * 3 + q] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
                                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
             }
-            if (flags) reached[inst] = 1;
+            b.reached[inst] = 1;
         }
         __syncthreads();
     }
@@ -341,14 +448,14 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 
 void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                            float* slots, uint8_t* reached, hipStream_t st) {
+                            float* slots, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
     const bool d = dL_ddepth != nullptr, a = dL_dalpha != nullptr;
-    if (d && a) hipLaunchKernelGGL((k_render_backward<true, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
-    else if (d) hipLaunchKernelGGL((k_render_backward<true, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
-    else if (a) hipLaunchKernelGGL((k_render_backward<false, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
-    else hipLaunchKernelGGL((k_render_backward<false, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, reached);
+    if (d && a) hipLaunchKernelGGL((k_render_backward<true, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else if (d) hipLaunchKernelGGL((k_render_backward<true, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else if (a) hipLaunchKernelGGL((k_render_backward<false, true>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else hipLaunchKernelGGL((k_render_backward<false, false>), dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
 }
 
 }  // namespace sr

@@ -60,6 +60,16 @@ def set_depth_gradient(enabled: bool) -> bool:
 def depth_gradient_enabled() -> bool:
     return _DEPTH_GRADIENT
 
+_BWD_KERNELS = {None: 0, "auto": 0, "wave": 1, "mfma": 2}
+
+
+def set_backward_kernel(which) -> str:
+    """Pin the backward blend kernel (A/B measurements, the test that compares the two): None / "auto" = chosen per launch by
+    the footprint, "wave" = pixel-per-lane, "mfma" = entry-per-lane.  Returns the previous setting."""
+    prev = _lib.load().sr_set_backward_kernel(_BWD_KERNELS[which])
+    return {0: "auto", 1: "wave", 2: "mfma"}[prev]
+
+
 # Per-device estimate of the instance count used to size the binning buffer BEFORE the count is known, so that
 # the forward never drains the GPU pipeline (include/splatraster.h: sr_forward).  Grows on demand.
 _CAPACITY = {}

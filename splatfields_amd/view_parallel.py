@@ -40,6 +40,73 @@ def _exchange(world: int) -> bool:
     return world > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
 
 
+class ExchangeStats:
+    """Optional instrumentation of the exchange part of a step (bench.py's N > 1 line): per step the time between issuing the
+    first collective of an exchange phase and the completion of its last one (events on the current stream; ``work.wait()``
+    orders it behind the collective), summed over the step's phases; the local compute that ran inside those windows (what
+    the exchange is overlapped with); and the bytes every GPU puts on the wire under the ring model RCCL uses on a
+    point-to-point xGMI node: all-reduce of S bytes 2 (G-1)/G S, all-gather / all-to-all of S bytes in total (G-1)/G S.
+    The caller brackets a step with ``end_step()``.  Off by default (no events are created)."""
+    enabled = False
+    _win: list = []        # (start, end) events of the current step's exchange windows
+    _inner: list = []      # (start, end) events of compute inside them
+    _bytes = 0.0
+    steps: list = []       # per finished step: (windows, inner, wire bytes)
+
+    @classmethod
+    def reset(cls, on: bool):
+        cls.enabled, cls._win, cls._inner, cls._bytes, cls.steps = bool(on), [], [], 0.0, []
+
+    @classmethod
+    def note(cls, kind: str, nbytes: float, world: int):
+        if cls.enabled and world > 0:
+            f = (world - 1) / world
+            cls._bytes += nbytes * (2.0 * f if kind == "all_reduce" else f)
+
+    @classmethod
+    def end_step(cls):
+        if cls.enabled:
+            cls.steps.append((cls._win, cls._inner, cls._bytes))
+            cls._win, cls._inner, cls._bytes = [], [], 0.0
+
+    @classmethod
+    def summary(cls) -> dict:
+        """Median per-step figures (ms, bytes); synchronises the recorded events."""
+        def med(xs):
+            xs = sorted(xs)
+            return xs[len(xs) // 2] if xs else 0.0
+        win = [sum(a.elapsed_time(b) for a, b in w) for w, _, _ in cls.steps]
+        inner = [sum(a.elapsed_time(b) for a, b in i) for _, i, _ in cls.steps]
+        return {"exchange_ms": med(win), "overlap_ms": med(inner), "wire_bytes_per_gpu": med([x for _, _, x in cls.steps]),
+                "steps": len(cls.steps)}
+
+
+class _Window:
+    """`with _Window(dev):` = the exchange window of one step; `with _Window(dev, inner=True):` = compute inside it."""
+
+    def __init__(self, dev, inner: bool = False):
+        self.on = ExchangeStats.enabled and torch.device(dev).type == "cuda"
+        self.inner = inner
+        self.dev = dev
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record(torch.cuda.current_stream(self.dev))
+            (ExchangeStats._inner if self.inner else ExchangeStats._win).append((self.a, self.b))
+        return False
+
+
+def _nbytes(t: torch.Tensor) -> float:
+    return float(t.numel() * t.element_size())
+
+
 def pack_gradients(grads: Sequence[torch.Tensor]):
     """One flat buffer holding ``grads`` back to back (one `cat` kernel) and, per tensor, a view of its segment."""
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -51,7 +118,7 @@ def pack_gradients(grads: Sequence[torch.Tensor]):
 
 
 def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, *, sh_param: torch.Tensor = None,
-                        sh_active_coeffs: int = None) -> None:
+                        sh_active_coeffs: int = None, restore_none: bool = False) -> None:
     """Mean over ranks of every ``.grad``: large tensors are all-reduced in place (largest first, so its ring starts while
     the rest is queued), the small ones travel packed in one buffer and ``p.grad`` is re-pointed at its segment.
     All collectives are issued asynchronously back to back and waited together.
@@ -61,13 +128,21 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, 
 
     ``sh_param`` / ``sh_active_coeffs``: while ``active_sh_degree`` is below the stored degree (reference
     scene/gaussian_model.py:118-120 raises it every 1000 iterations) the gradient of the inactive bands is exactly zero on
-    every rank; only the leading ``sh_active_coeffs`` coefficients of ``sh_param.grad`` [N, K, 3] are exchanged then."""
+    every rank; only the leading ``sh_active_coeffs`` coefficients of ``sh_param.grad`` [N, K, 3] are exchanged then.
+
+    A parameter that has no gradient on ANY rank (frozen, or unused by every view of the step) ends up with a zero gradient
+    here, whereas the single-process loop leaves ``grad = None`` and Adam skips it (its moments do not decay).  Pass only
+    parameters that take part in the loss, or ``restore_none=True``: a has-gradient flag per parameter rides in the packed
+    buffer and ``grad`` is set back to ``None`` where no rank had one (costs one small device-to-host read after the
+    collectives)."""
     if not _exchange(world):
         return
     params = list(params)
+    had_grad = [p.grad is not None for p in params]
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
+    all_params = params
     sh_slice = None
     if sh_param is not None and sh_active_coeffs is not None and sh_param.grad is not None and sh_param.grad.dim() == 3 \
             and 0 < sh_active_coeffs < sh_param.grad.shape[1]:
@@ -79,19 +154,29 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, 
     # RCCL averages in the collective itself (no extra pass over 236 B/splat); gloo (CPU tests) has no AVG
     avg = dist.get_backend(group) == "nccl"
     op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-    works = [dist.all_reduce(p.grad, op=op, group=group, async_op=True) for p in big]
-    if sh_slice is not None:
-        works.append(dist.all_reduce(sh_slice, op=op, group=group, async_op=True))
-    by_dtype = {}
-    for p in small:
-        by_dtype.setdefault(p.grad.dtype, []).append(p)
-    packed = []
-    for ps in by_dtype.values():
-        flat, views = pack_gradients([p.grad for p in ps])
-        works.append(dist.all_reduce(flat, op=op, group=group, async_op=True))
-        packed.append((ps, flat, views))
-    for w in works:
-        w.wait()
+    dev = all_params[0].grad.device if all_params else "cpu"
+    flags = None
+    with _Window(dev):
+        works = [dist.all_reduce(p.grad, op=op, group=group, async_op=True) for p in big]
+        for p in big:
+            ExchangeStats.note("all_reduce", _nbytes(p.grad), world)
+        if sh_slice is not None:
+            works.append(dist.all_reduce(sh_slice, op=op, group=group, async_op=True))
+            ExchangeStats.note("all_reduce", _nbytes(sh_slice), world)
+        by_dtype = {}
+        for p in small:
+            by_dtype.setdefault(p.grad.dtype, []).append(p)
+        packed = []
+        for ps in by_dtype.values():
+            flat, views = pack_gradients([p.grad for p in ps])
+            works.append(dist.all_reduce(flat, op=op, group=group, async_op=True))
+            ExchangeStats.note("all_reduce", _nbytes(flat), world)
+            packed.append((ps, flat, views))
+        if restore_none:
+            flags = torch.tensor([1.0 if h else 0.0 for h in had_grad], dtype=torch.float32, device=dev)
+            works.append(dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()
     if not avg:
         scale = 1.0 / world
         for p in big:
@@ -105,6 +190,10 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, 
             p.grad = v
     if sh_slice is not None:
         sh_param.grad[:, :sh_slice.shape[1]].copy_(sh_slice)
+    if flags is not None:
+        for p, f in zip(all_params, flags.tolist()):
+            if f == 0.0:
+                p.grad = None   # no rank had a gradient for it: as in the single-process loop, the optimizer skips it
 
 
 def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
@@ -159,18 +248,22 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     campos_all = _campos_of(cams, dev)
     if _exchange(world):
         gathered = torch.empty(world, len(mine), n, 3, dtype=torch.float32, device=dev)
-        # the collectives run in issue order on RCCL's stream: the all-gather first (the SH rebuild needs it), then ONE
-        # all-reduce of the four geometric gradients packed back to back (44 B/splat), which overlaps the SH rebuild
-        gather_work = dist.all_gather_into_tensor(gathered.view(-1), dcol_local.view(-1), group=group, async_op=True)
-        flat, views = pack_gradients([params[k].grad for k in names])
-        reduce_work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         # gathered[r, slot] is view r + slot*world
         order = [r + sl * world for r in range(world) for sl in range(len(mine))]
         dcol_all = gathered.reshape(world * len(mine), n, 3)
         campos_used = campos_all if order == list(range(V)) else campos_all[torch.tensor(order, device=dev)]
-        gather_work.wait()
-        params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
-        reduce_work.wait()
+        with _Window(dev):
+            # the collectives run in issue order on RCCL's stream: the all-gather first (the SH rebuild needs it), then ONE
+            # all-reduce of the four geometric gradients packed back to back (44 B/splat), which overlaps the SH rebuild
+            gather_work = dist.all_gather_into_tensor(gathered.view(-1), dcol_local.view(-1), group=group, async_op=True)
+            ExchangeStats.note("all_gather", _nbytes(gathered), world)
+            flat, views = pack_gradients([params[k].grad for k in names])
+            reduce_work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            ExchangeStats.note("all_reduce", _nbytes(flat), world)
+            gather_work.wait()
+            with _Window(dev, inner=True):
+                params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
+            reduce_work.wait()
         for k, v in zip(names, views):
             params[k].grad = v
     else:
@@ -262,7 +355,9 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
         send.view(V, shard, 3)[:, :n_own].copy_(col_own)
     if _exchange(world):
         recv = torch.empty_like(send)
-        _all_to_all(recv, send, group)
+        with _Window(dev):
+            _all_to_all(recv, send, group)
+            ExchangeStats.note("all_to_all", _nbytes(send), world)
     else:
         recv = send
     # recv[s, slot] = colours of shard s for my view `slot`
@@ -292,7 +387,9 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
     # 3. colour gradients back to the shard owners; SH gradient (and the view-direction term) of my shard from all views
     if _exchange(world):
         dcol_recv = torch.empty_like(dcol_send)
-        _all_to_all(dcol_recv, dcol_send, group)
+        with _Window(dev):
+            _all_to_all(dcol_recv, dcol_send, group)
+            ExchangeStats.note("all_to_all", _nbytes(dcol_send), world)
     else:
         dcol_recv = dcol_send
     d_shs = None
@@ -305,8 +402,10 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
 
     # 4. the geometric gradients of all views
     if _exchange(world):
-        flat, views = pack_gradients([params[name].grad for name in names])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        with _Window(dev):
+            flat, views = pack_gradients([params[name].grad for name in names])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            ExchangeStats.note("all_reduce", _nbytes(flat), world)
         for name, v_ in zip(names, views):
             params[name].grad = v_
     return lo, hi, d_shs

@@ -28,17 +28,56 @@ def test_stage_bytes_are_positive_and_scale_with_their_units():
 
 
 def test_roofline_valu_is_reproducible_from_the_committed_counters():
-    """bench.py's issue-side roofline comes from profiles/pmc_sq.json (rocprofv3 SQ counter passes): pure arithmetic."""
+    """bench.py's issue-side roofline comes from profiles/pmc_sq.json (rocprofv3 SQ counter passes): pure arithmetic against
+    hardware ceilings (2 cycles per wave-level VALU instruction per SIMD-32, 157.3 TFLOP/s fp32), nothing self-referential."""
     import json
-    wl = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))["_workload"]
-    r = bench.valu_roofline(wl, {"render_forward": 0.12, "render_backward": 0.28})
-    assert r is not None and r["simds"] == 1024
+    pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+    wl = dict(pj["_workload"])
+    stage_ms = {"render_forward": 0.12, "render_backward": 0.28}
+    r = bench.valu_roofline(wl, stage_ms, pairs_blended=36.9e6, check_hash=False)
+    assert r is not None and r["simds"] == 1024 and r["valu_issue_cycles_per_wave_inst"] == 2.0
     for stage in ("render_forward", "render_backward"):
-        s = r[stage]
-        assert s["wave_valu_insts_per_launch"] > 1e7 and s["kernel_cycles"] > 1e5
-        assert abs(s["cycles_per_valu_inst_per_simd"] - s["kernel_cycles"] * 1024 / s["wave_valu_insts_per_launch"]) < 1e-9
-        assert 0.0 < s["frac"] <= 1.0
-    # the entry-per-lane backward issues fewer instructions than the forward has per launch x 2, at a lower issue rate
+        s, c = r[stage], pj[stage]
+        cycles = c["SQ_BUSY_CYCLES"] / 32.0
+        assert abs(s["kernel_cycles"] - cycles) < 1e-6
+        assert abs(s["valu_issue_frac"] - c["SQ_INSTS_VALU"] * 2.0 / 1024.0 / cycles) < 1e-12 and s["frac"] == s["valu_issue_frac"]
+        assert 0.0 < s["valu_issue_frac"] < 1.0
+        sh = s["wave_cycle_shares"]
+        assert abs(sh["parked"] - c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]) < 1e-12
+        assert 0.9 < sh["parked"] + sh["issue_stalled"] + sh["issuing"] < 1.1   # the three buckets partition the wave cycles
+        flop = {"render_forward": 30.0, "render_backward": 90.0}[stage]
+        assert abs(s["useful_flop_frac"] - 36.9e6 * flop / (stage_ms[stage] * 1e-3) / 157.3e12) < 1e-12
     assert r["render_backward"]["mfma_insts_per_launch"] > 0 and r["render_forward"]["mfma_insts_per_launch"] == 0
     # another workload has no recorded counters
-    assert bench.valu_roofline(dict(wl, splats=123), {}) is None
+    assert bench.valu_roofline(dict(wl, splats=123), {}, check_hash=False) is None
+
+
+def test_recorded_counters_are_refused_when_the_kernel_sources_changed(tmp_path, monkeypatch):
+    """profiles/traffic.json and pmc_sq.json carry the hash of the kernel sources they were measured on (build.source_hash);
+    bench.py refuses them for other sources instead of quoting stale numbers."""
+    import json
+    from splatfields_amd.build import source_hash
+    wl = {"splats": 1000, "width": 64, "height": 64, "color": "sh", "sh_degree": 3, "mean_scale": None}
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    good = {"_workload": dict(wl), "_source_hash": source_hash(), "render_backward": 123.0}
+    (prof / "traffic.json").write_text(json.dumps(good))
+    pj, why = bench.recorded_counters("traffic.json", wl)
+    assert why is None and pj["render_backward"] == 123.0
+    (prof / "traffic.json").write_text(json.dumps(dict(good, _source_hash="0123456789abcdef")))
+    pj, why = bench.recorded_counters("traffic.json", wl)
+    assert pj is None and "sources changed" in why
+    pj, why = bench.recorded_counters("traffic.json", dict(wl, splats=7))
+    assert pj is None and "another workload" in why
+    assert bench.recorded_counters("missing.json", wl) == (None, "no recorded counters")
+    # a stale SQ file turns into an explicit marker, not into numbers
+    (prof / "pmc_sq.json").write_text(json.dumps({"_workload": dict(wl), "_source_hash": "0" * 16, "render_forward": {}}))
+    assert "stale" in bench.valu_roofline(wl, {})
+
+
+def test_median_of_per_step_times():
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5 and bench.median([]) == 0.0
+    # one slow step (a box hiccup) moves the mean, not the median
+    xs = [0.70] * 19 + [1.40]
+    assert bench.median(xs) == 0.70 and sum(xs) / len(xs) > 0.73

@@ -225,16 +225,19 @@ def test_image_with_exactly_16384_tiles(hip_device):
 
 
 @pytest.mark.parametrize("n,w,h,scale", [(6000, 208, 160, None), (3000, 160, 128, 0.08)])
-def test_both_backward_blend_kernels_agree(hip_device, monkeypatch, n, w, h, scale):
+def test_both_backward_blend_kernels_agree(hip_device, n, w, h, scale):
     """sr_backward picks the entry-per-lane (MFMA) or the pixel-per-lane (butterfly) kernel by the mean footprint; both write
-    the same gradient slots.  Pinned through SPLATRASTER_BWD they must agree to fp32 round-off (different summation order)
+    the same gradient slots.  Pinned through sr_set_backward_kernel they must agree to fp32 round-off (different summation order)
     and each must match the oracle, on a small-footprint and on a large-footprint scene."""
     sp, cam, st, grads = make_scene(n, w, h, mean_scale=scale, view=2)
     res = {}
-    for kernel in ("mfma", "wave"):
-        monkeypatch.setenv("SPLATRASTER_BWD", kernel)
-        _, res[kernel] = run_hip(sp, st, grads, hip_device)
-    monkeypatch.delenv("SPLATRASTER_BWD")
+    from splatfields_amd.rasterizer import set_backward_kernel
+    try:
+        for kernel in ("mfma", "wave"):
+            set_backward_kernel(kernel)
+            _, res[kernel] = run_hip(sp, st, grads, hip_device)
+    finally:
+        set_backward_kernel(None)
     _, auto = run_hip(sp, st, grads, hip_device)
     _, gr = O.fwd_bwd(sp, st, *grads, use_sh=True, dtype=torch.float64)
     for k in gr:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU diagnostic: gradients of the MFMA backward blend (blend_bwd.hip) against round 1's pixel-per-lane kernel
-(SPLATRASTER_BWD=wave) and against the C oracle, on a few scene regimes.  Usage: python tools/bwd_compare.py [fast]"""
+(set_backward_kernel("wave")) and against the C oracle, on a few scene regimes.  Usage: python tools/bwd_compare.py [fast]"""
 import os
 import sys
 import time
@@ -13,12 +13,12 @@ from tests.helpers import grad_error, make_scene, run_hip  # noqa: E402
 
 
 def grads_with(kernel, sp, st, grads, dev, use_sh=True):
-    if kernel:
-        os.environ["SPLATRASTER_BWD"] = kernel
-    else:
-        os.environ.pop("SPLATRASTER_BWD", None)
-    out, g = run_hip(sp, st, grads, dev, use_sh=use_sh)
-    os.environ.pop("SPLATRASTER_BWD", None)
+    from splatfields_amd.rasterizer import set_backward_kernel
+    set_backward_kernel(kernel)
+    try:
+        out, g = run_hip(sp, st, grads, dev, use_sh=use_sh)
+    finally:
+        set_backward_kernel(None)
     return out, g
 
 

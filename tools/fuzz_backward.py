@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.helpers import grad_error, make_scene, run_hip  # noqa: E402
+from splatfields_amd.rasterizer import set_backward_kernel  # noqa: E402
 
 
 def main():
@@ -30,10 +31,10 @@ def main():
                                         seed=1000 + it)
         res = {}
         for kernel in ("mfma", "wave", "mfma"):
-            os.environ["SPLATRASTER_BWD"] = kernel
+            set_backward_kernel(kernel)
             _, g = run_hip(sp, st, grads, dev, use_sh=use_sh, with_depth=wd, with_alpha=wa)
             res.setdefault(kernel, []).append(g)
-        os.environ.pop("SPLATRASTER_BWD")
+        set_backward_kernel(None)
         e = max(grad_error(res["mfma"][0][k], res["wave"][0][k]) for k in res["wave"][0])
         repro = all(torch.equal(res["mfma"][0][k], res["mfma"][1][k]) for k in res["wave"][0])
         finite = all(torch.isfinite(v).all() for v in res["mfma"][0].values())

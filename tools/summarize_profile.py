@@ -14,7 +14,11 @@ import json
 import os
 import re
 import shutil
+import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from splatfields_amd.build import source_hash  # noqa: E402  (the kernel sources these counters were collected from)
 
 # kernel name prefix -> pipeline stage of bench.py / sr_profile_stage_name
 STAGE_OF = [
@@ -82,7 +86,8 @@ def main():
         cfg = bench["config"]
         sq = {"_workload": {"splats": cfg["splats"], "width": cfg["width"], "height": cfg["height"], "color": "sh", "sh_degree": 3,
                             "mean_scale": None},
-              "_source": "%s_pmc.json (rocprofv3 --pmc SQ_* passes of tools/profile.sh, means per launch)" % a.prefix}
+              "_source": "%s_pmc.json (rocprofv3 --pmc SQ_* passes of tools/profile.sh, means per launch)" % a.prefix,
+              "_source_hash": source_hash()}
         for k, d in out.items():
             for prefix, s in (("sr::k_render_forward", "render_forward"), ("sr::k_render_backward", "render_backward")):
                 if k.startswith(prefix):
@@ -107,6 +112,7 @@ def main():
         cfg = bench["config"]
         t["_workload"] = {"splats": cfg["splats"], "width": cfg["width"], "height": cfg["height"], "color": "sh",
                           "sh_degree": 3}
+        t["_source_hash"] = source_hash()
         json.dump(t, open(a.traffic, "w"), indent=1)
         for s, v in stage.items():
             print("%-20s %8.1f MB" % (s, v / 1e6))
