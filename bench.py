@@ -259,9 +259,15 @@ def deform_network_probe():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     keep = ["splats", "image", "dtype", "net_fwd_bwd_ms", "net_fwd_bwd_fused_mlps_ms", "rasterizer_fwd_bwd_ms", "full_step_ms",
             "full_step_fused_mlps_ms", "net_forward_ms", "net_forward_fused_mlps_ms", "net_share_of_step", "fused_forward_max_rel_diff",
-            "fused_training_max_rel_grad_diff_parameters", "fused_training_xyz_grad_median_rel_diff"]
+            "fused_training_max_rel_grad_diff_parameters", "fused_training_xyz_grad_median_rel_diff",
+            "product_net_fwd_bwd_ms", "product_full_step_ms", "product_net_forward_ms", "product_decoderfree_net_fwd_bwd_ms",
+            "product_decoderfree_full_step_ms", "product_decoderfree_net_forward_ms", "product_graphed_net_fwd_bwd_ms",
+            "product_graphed_full_step_ms", "product_decoderfree_graphed_net_fwd_bwd_ms", "product_decoderfree_graphed_full_step_ms",
+            "product_graphed_error", "product_decoderfree_graphed_error"]
     res = {k: d[k] for k in keep if k in d}
-    res["name"] = "4-D config: deform network (stand-in of the reference's shapes), PyTorch-ROCm vs fused MLP kernels"
+    res["name"] = ("4-D config: deform network (stand-in of the reference's shapes), PyTorch-ROCm vs fused MLP kernels; product_* = "
+                   "splatfields_amd.deform_field.SplatFields (tri-plane lookup, ResField composition and MLPs on HIP kernels) with the same "
+                   "stand-in plane decoder, product_decoderfree_* = the sampler owns its planes")
     return res
 
 

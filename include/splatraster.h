@@ -310,6 +310,40 @@ typedef struct SrMlpGradJob {
 size_t sr_mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob* jobs);   /* 0 for an unsupported job list */
 int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* ResField weights of the current frame for all layers of one network in one launch (reference utils/resfields.py:185,229,
+ * 294-300,378-405 in the configuration GeneralMLP builds -- compression 'vm', mode 'lookup', fuse 'add'):
+ *   out[j] = w[j] + sum_k weights_t[frame * rank + k] * matrix_t[k * count + j],   j < count = out_features * in_features.
+ * `frame` points at an int64 on the device (the reference derives frame_id on the device: no host synchronisation).
+ * Backward, given d_out = dL/d out: d_matrix_t[k * count + j] = weights_t[frame * rank + k] * d_out[j];
+ * d_weights_t [capacity, rank] = 0 except row `frame` = matrix_t . d_out (summed in a fixed order); dL/dw = d_out itself.
+ * count a multiple of 4, 16-byte aligned arrays, rank <= SR_RESFIELD_MAX_RANK. */
+#define SR_RESFIELD_MAX_JOBS 16
+#define SR_RESFIELD_MAX_RANK 64
+typedef struct SrResFieldJob {
+    const float* w; const float* weights_t; const float* matrix_t; float* out;    /* forward */
+    const float* d_out; float* d_matrix_t; float* d_weights_t;                     /* backward (either output may be NULL) */
+    int count, rank, capacity;
+} SrResFieldJob;
+int sr_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* hip_stream);
+size_t sr_resfield_backward_workspace(int n_jobs, const SrResFieldJob* jobs);     /* 0 for an unsupported job list */
+int sr_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* workspace, size_t workspace_bytes,
+                         void* hip_stream);
+
+/* Tri-plane feature lookup of the deform network's encoder -- the per-point half of the reference's VarTriPlaneEncoder.forward
+ * (scene/tripFields.py:430-436): F.grid_sample (bilinear, zero padding, align_corners = False) of three planes [3, C, H, W] at
+ * the (x, y), (y, z), (z, x) projections of the points, features concatenated plane-major: out [N, 3 C].  C a multiple of 4.
+ * The plane generator (the reference's diffusers-based decoder, :176-204) is the caller's; it hands over `planes`.
+ * `planes_texel_major` [3, H, W, C] is written by the forward (a transposed copy: a corner becomes C contiguous floats) and
+ * read again by the backward.
+ * Backward: dL_dpoints [N, 3] (gather) and / or dL_dplanes [3, C, H, W] (either may be NULL).  The plane gradient is
+ * accumulated in 64-bit fixed point with integer atomics -- bit-reproducible, no floating-point atomics; `fixed` holds
+ * sr_triplane_fixed_bytes(C, H, W) bytes (needed only with dL_dplanes). */
+size_t sr_triplane_fixed_bytes(int channels, int height, int width);
+int sr_triplane_forward(int n_points, int channels, int height, int width, const float* planes, float* planes_texel_major,
+                        const float* points, float* out, void* hip_stream);
+int sr_triplane_backward(int n_points, int channels, int height, int width, const float* planes_texel_major, const float* points,
+                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* fixed, void* hip_stream);
+
 /* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
  * (`instances` = the capacity the binning buffer was carved for):
  *   out[0]  geom:    tile_start  uint32[tiles + 1]   first list entry of every 16x16 tile (row-major tiles)

@@ -52,6 +52,12 @@ class SrMlpGradJob(C.Structure):
                 ("x_row", C.c_int), ("k", C.c_int), ("dw_row", C.c_int), ("dw_col0", C.c_int)]
 
 
+class SrResFieldJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("weights_t", C.c_void_p), ("matrix_t", C.c_void_p), ("out", C.c_void_p), ("d_out", C.c_void_p),
+                ("d_matrix_t", C.c_void_p), ("d_weights_t", C.c_void_p), ("count", C.c_int), ("rank", C.c_int), ("capacity", C.c_int)]
+
+
+RESFIELD_MAX_JOBS, RESFIELD_MAX_RANK = 16, 64
 MLP_MAX_GRAD_JOBS, MLP_MAX_GRAD_TASKS = 16, 128
 MLP_MAX_PACK_JOBS = 32
 MLP_MAX_OPS, MLP_NONE, MLP_LEAKY, MLP_MASK = 24, 0, 1, 2      # include/splatraster.h: SR_MLP_*
@@ -90,6 +96,13 @@ SYMBOLS = {
     "sr_mlp_weight_grad_workspace": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob)]),
     "sr_mlp_weight_grad": (C.c_int, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "sr_mlp_chain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SrMlpOp), C.c_float, C.c_void_p]),
+    "sr_resfield_compose": (C.c_int, [C.c_int, C.POINTER(SrResFieldJob), C.c_void_p, C.c_void_p]),
+    "sr_resfield_backward_workspace": (C.c_size_t, [C.c_int, C.POINTER(SrResFieldJob)]),
+    "sr_resfield_backward": (C.c_int, [C.c_int, C.POINTER(SrResFieldJob), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sr_triplane_fixed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sr_triplane_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_triplane_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "sr_debug_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(C.c_size_t)]),
     "sr_debug_backward_stats": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sr_profile_enable": (C.c_int, [C.c_int]),

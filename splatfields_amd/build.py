@@ -12,7 +12,7 @@ LIB_PATH = PKG_DIR / "libsplatraster.so"
 # same ABI with the work counters of the backward blend compiled in (-DSR_BWD_STATS): measurement aid of bench.py
 # (pairs_evaluated / pairs_blended), never the timed path
 STATS_LIB_PATH = PKG_DIR / "libsplatraster_stats.so"
-SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "blend_bwd.hip", "knn.hip", "sh.hip", "densify.hip", "mlp.hip"]
+SOURCES = ["api.hip", "preprocess.hip", "binning.hip", "render.hip", "blend_bwd.hip", "knn.hip", "sh.hip", "densify.hip", "mlp.hip", "triplane.hip"]
 HEADERS = ["common.h", "kernels.h", "expand.h", "sh_stage.h", "quadmask.h", "../../include/splatraster.h"]
 
 

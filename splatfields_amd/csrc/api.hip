@@ -21,7 +21,8 @@ int check_hip(hipError_t e, const char* what) {
 }
 
 // ---- optional per-stage timing (HIP events on the launch stream) ----
-struct ProfRec { int stage; hipEvent_t a, b; };
+struct ProfRec { int stage; hipEvent_t a, b; bool ended; unsigned long long serial; };
+unsigned long long g_prof_serial = 0;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mutex;   // host threads rendering on their own streams may record concurrently
@@ -31,15 +32,25 @@ struct StageTimer {
     int idx = -1; hipStream_t st;
     StageTimer(int stage, hipStream_t s) : st(s) {
         if (!g_prof_on) return;
-        ProfRec r; r.stage = stage;
+        ProfRec r; r.stage = stage; r.ended = false;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         hipEventRecord(r.a, st);
         std::lock_guard<std::mutex> lock(g_prof_mutex);
-        g_prof.push_back(r); idx = (int)g_prof.size() - 1;
+        serial = ++g_prof_serial;
+        r.serial = serial;
+        g_prof.push_back(r); idx = 0;
         end = r.b;
     }
     hipEvent_t end = nullptr;
-    ~StageTimer() { if (idx >= 0) hipEventRecord(end, st); }
+    unsigned long long serial = 0;
+    // the end event is recorded under the same mutex that sr_profile_collect holds while it walks (and destroys) the list:
+    // a record whose timer is still open is left alone by the collector
+    ~StageTimer() {
+        if (idx < 0) return;
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        for (auto& r : g_prof)
+            if (r.serial == serial) { hipEventRecord(end, st); r.ended = true; break; }
+    }
 };
 
 // Pinned word + event per (host thread, device) for the asynchronous instance-count read-back of sr_forward
@@ -397,6 +408,46 @@ int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void*
     return check_hip(hipGetLastError(), "mlp_weight_grad");
 }
 
+int sr_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* hip_stream) {
+    if (sr::launch_resfield_compose(n_jobs, jobs, frame, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_resfield_compose: unsupported job list (<= SR_RESFIELD_MAX_JOBS jobs, count a multiple of 4, 16-byte aligned "
+                    "arrays, 1 <= rank <= SR_RESFIELD_MAX_RANK) or null frame pointer");
+    return check_hip(hipGetLastError(), "resfield_compose");
+}
+
+size_t sr_resfield_backward_workspace(int n_jobs, const SrResFieldJob* jobs) { return sr::resfield_backward_workspace(n_jobs, jobs); }
+
+int sr_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* workspace, size_t workspace_bytes,
+                         void* hip_stream) {
+    if (sr::launch_resfield_backward(n_jobs, jobs, frame, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_resfield_backward: unsupported job list, null frame pointer or workspace too small");
+    return check_hip(hipGetLastError(), "resfield_backward");
+}
+
+size_t sr_triplane_fixed_bytes(int channels, int height, int width) {
+    if (channels <= 0 || height <= 0 || width <= 0) return 0;
+    return ((size_t)3 * height * width * channels + 1) * sizeof(unsigned long long);
+}
+
+int sr_triplane_forward(int n_points, int channels, int height, int width, const float* planes, float* planes_texel_major,
+                        const float* points, float* out, void* hip_stream) {
+    if (n_points < 0 || !planes || !planes_texel_major || (n_points > 0 && (!points || !out))) return fail("bad arguments to sr_triplane_forward");
+    if (sr::launch_triplane_forward(n_points, channels, height, width, planes, planes_texel_major, points, out, static_cast<hipStream_t>(hip_stream)))
+        return fail("sr_triplane_forward: channels must be a positive multiple of 4, height * width <= 2^30");
+    return check_hip(hipGetLastError(), "triplane_forward");
+}
+
+int sr_triplane_backward(int n_points, int channels, int height, int width, const float* planes_texel_major, const float* points,
+                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* fixed, void* hip_stream) {
+    if (n_points < 0 || !planes_texel_major || (n_points > 0 && (!points || !dL_dout)) || (dL_dplanes && !fixed))
+        return fail("bad arguments to sr_triplane_backward");
+    const int rc = sr::launch_triplane_backward(n_points, channels, height, width, planes_texel_major, points, dL_dout, dL_dplanes, dL_dpoints,
+                                                fixed, static_cast<hipStream_t>(hip_stream));
+    if (rc == 1) return fail("sr_triplane_backward: channels must be a positive multiple of 4, height * width <= 2^30");
+    if (rc) return fail("sr_triplane_backward: clearing the accumulators failed");
+    return check_hip(hipGetLastError(), "triplane_backward");
+}
+
 int sr_debug_layout(int n, int h, int w, long long instances, size_t* out4) {
     if (!out4 || n < 0 || h <= 0 || w <= 0 || instances < 0) return fail("bad arguments to sr_debug_layout");
     sr::Geom g; sr::Binning b;
@@ -420,7 +471,9 @@ int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
 
 int sr_profile_collect(double* ms_sum, long long* launches) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
+    std::vector<ProfRec> open;
     for (auto& r : g_prof) {
+        if (!r.ended) { open.push_back(r); continue; }   // another host thread is inside this stage right now
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             if (ms_sum) ms_sum[r.stage] += ms;
@@ -428,7 +481,7 @@ int sr_profile_collect(double* ms_sum, long long* launches) {
         }
         hipEventDestroy(r.a); hipEventDestroy(r.b);
     }
-    g_prof.clear();
+    g_prof.swap(open);
     return 0;
 }
 

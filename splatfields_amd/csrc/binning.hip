@@ -13,6 +13,7 @@
 //    scatter (bit-reproducible).
 // HBM traffic per instance: 8 B scatter write + 8 B sort read + 4 B sorted write, versus 6 radix passes x 24 B for a
 // global 44-bit LSD sort.
+#include <atomic>
 #include "kernels.h"
 #include "expand.h"
 
@@ -21,12 +22,13 @@ namespace sr {
 // Kernels whose dynamic LDS can exceed the 64 KiB default limit need the attribute raised once per device (it belongs to
 // the device's copy of the kernel).  `slot` = a small fixed id per kernel.
 static void allow_dynamic_lds(const void* kernel, int slot, int bytes) {
-    static bool done[8][64] = {};
+    static std::atomic<bool> done[8][64];   // zero-initialised; host threads may race here, the attribute call is idempotent
     int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && done[slot][dev]) return;
-    hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (dev >= 0 && dev < 64) done[slot][dev] = true;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (dev >= 0 && dev < 64 && done[slot][dev].load(std::memory_order_acquire)) return;
+    // a failure is not cached: the launch that needs the larger limit then fails with its own error, and the next call retries
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (dev >= 0 && dev < 64) done[slot][dev].store(true, std::memory_order_release);
 }
 
 // ---- atomic-free per-tile counts: count matrix [chunk][tile] built with LDS atomics only ----------

@@ -59,6 +59,15 @@ int launch_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, v
 int launch_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, hipStream_t st);
 int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float slope, hipStream_t st);
 
+int launch_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, hipStream_t st);
+size_t resfield_backward_workspace(int n_jobs, const SrResFieldJob* jobs);
+int launch_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// triplane.hip
+int launch_triplane_forward(int N, int C, int H, int W, const float* planes_chw, float* planes_hwc, const float* pts, float* out, hipStream_t st);
+int launch_triplane_backward(int N, int C, int H, int W, const float* planes_hwc, const float* pts, const float* g, float* d_planes_chw,
+                             float* d_pts, void* fixed, hipStream_t st);
+
 // knn.hip
 size_t knn_workspace_bytes(int n);
 void launch_knn3(int n, const float* pts, float* out, void* workspace, hipStream_t st);

@@ -412,3 +412,133 @@ int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* o
 }
 
 }  // namespace sr
+
+// ------------------------------------------------------------------------------------------------------------------------
+// ResField weights of ONE frame for all layers of a network (reference utils/resfields.py:185,229,294-300,378-405 in the
+// configuration GeneralMLP builds: compression 'vm', mode 'lookup', fuse 'add'):
+//     W_eff[j] = W[j] + sum_k weights_t[frame][k] * matrix_t[k][j],      j < out * in
+// The reference materialises the [capacity, out * in] matrix of EVERY frame per call and indexes it; composing only the
+// current frame with PyTorch ops costs an index, a [1 x rank] x [rank x out in] product and an add per layer, and twice that
+// backward -- about 240 small launches per step of the six-network deform field.  Here: one launch per network forward,
+// two backward (d matrix_t = coeff (x) dW_eff written in place of an outer-product kernel per layer; d weights_t[frame] =
+// matrix_t . dW_eff by a fixed-order two-stage reduction; d W = dW_eff needs no kernel at all).  Memory-bound: matrix_t is
+// rank x out x in floats (4.5 MB for a 128 x 222 layer at the reference's rank 40).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace sr {
+
+struct ResFieldK { SrResFieldJob job[SR_RESFIELD_MAX_JOBS]; const long long* frame; float* part; int blocks_per_job; };
+
+constexpr int kRfPerBlock = kBlock * 4;   // elements of W per workgroup
+
+__global__ void __launch_bounds__(kBlock) k_resfield_compose(const ResFieldK P) {
+    const SrResFieldJob J = P.job[blockIdx.y];
+    const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
+    if (4 * j4 >= J.count) return;
+    const long long f = *P.frame;
+    const float* coeff = J.weights_t + (size_t)f * J.rank;
+    const int q = J.count >> 2;
+    const float4* M = reinterpret_cast<const float4*>(J.matrix_t) + j4;
+    float4 acc = reinterpret_cast<const float4*>(J.w)[j4];
+    int k = 0;
+    for (; k + 4 <= J.rank; k += 4) {      // four independent loads in flight
+        const float4 m0 = M[(size_t)k * q], m1 = M[(size_t)(k + 1) * q], m2 = M[(size_t)(k + 2) * q], m3 = M[(size_t)(k + 3) * q];
+        const float c0 = coeff[k], c1 = coeff[k + 1], c2 = coeff[k + 2], c3 = coeff[k + 3];
+        acc.x += c0 * m0.x + c1 * m1.x + c2 * m2.x + c3 * m3.x; acc.y += c0 * m0.y + c1 * m1.y + c2 * m2.y + c3 * m3.y;
+        acc.z += c0 * m0.z + c1 * m1.z + c2 * m2.z + c3 * m3.z; acc.w += c0 * m0.w + c1 * m1.w + c2 * m2.w + c3 * m3.w;
+    }
+    for (; k < J.rank; ++k) {
+        const float4 m = M[(size_t)k * q];
+        const float c = coeff[k];
+        acc.x += c * m.x; acc.y += c * m.y; acc.z += c * m.z; acc.w += c * m.w;
+    }
+    reinterpret_cast<float4*>(J.out)[j4] = acc;
+}
+
+// d_matrix_t[k][j] = coeff[k] * g[j]; partial sums of matrix_t[k][.] . g over this workgroup's 1024 elements -> part
+__global__ void __launch_bounds__(kBlock) k_resfield_backward(const ResFieldK P) {
+    __shared__ float s_part[4][SR_RESFIELD_MAX_RANK];
+    const SrResFieldJob J = P.job[blockIdx.y];
+    if (blockIdx.x * kRfPerBlock >= J.count) return;   // whole workgroup
+    const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
+    const bool in = 4 * j4 < J.count;
+    const long long f = *P.frame;
+    const float* coeff = J.weights_t + (size_t)f * J.rank;
+    const int q = J.count >> 2;
+    const float4 g = in ? reinterpret_cast<const float4*>(J.d_out)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < J.rank; ++k) {
+        float dot = 0.0f;
+        if (in) {
+            const float4 m = reinterpret_cast<const float4*>(J.matrix_t)[(size_t)k * q + j4];
+            const float c = coeff[k];
+            if (J.d_matrix_t) reinterpret_cast<float4*>(J.d_matrix_t)[(size_t)k * q + j4] = make_float4(c * g.x, c * g.y, c * g.z, c * g.w);
+            dot = (m.x * g.x + m.y * g.y) + (m.z * g.z + m.w * g.w);
+        }
+        const float tot = wave_sum_to_lane63(dot);
+        if (lane_id() == 63) s_part[wave_id()][k] = tot;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < J.rank)
+        P.part[((size_t)blockIdx.y * P.blocks_per_job + blockIdx.x) * SR_RESFIELD_MAX_RANK + threadIdx.x] =
+            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+}
+
+// d_weights_t [capacity, rank]: zero except row `frame` = sum of the workgroups' partial sums in launch order
+__global__ void __launch_bounds__(kBlock) k_resfield_finish(const ResFieldK P) {
+    const SrResFieldJob J = P.job[blockIdx.x];
+    if (!J.d_weights_t) return;
+    const long long f = *P.frame;
+    const int nb = (J.count + kRfPerBlock - 1) / kRfPerBlock;
+    for (int i = threadIdx.x; i < J.capacity * J.rank; i += kBlock) {
+        float v = 0.0f;
+        if (i / J.rank == (int)f) {
+            const int k = i - (int)f * J.rank;
+            for (int b = 0; b < nb; ++b) v += P.part[((size_t)blockIdx.x * P.blocks_per_job + b) * SR_RESFIELD_MAX_RANK + k];
+        }
+        J.d_weights_t[i] = v;
+    }
+}
+
+static int resfield_check(int n_jobs, const SrResFieldJob* jobs, bool backward, int* max_count) {
+    if (n_jobs < 1 || n_jobs > SR_RESFIELD_MAX_JOBS || !jobs) return 1;
+    int mc = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const SrResFieldJob& s = jobs[j];
+        if (s.count < 4 || (s.count & 3) || s.rank < 1 || s.rank > SR_RESFIELD_MAX_RANK || s.capacity < 1 || !s.weights_t || !s.matrix_t) return 1;
+        if ((reinterpret_cast<uintptr_t>(s.matrix_t) & 15u)) return 1;
+        if (!backward && (!s.w || !s.out || ((reinterpret_cast<uintptr_t>(s.w) | reinterpret_cast<uintptr_t>(s.out)) & 15u))) return 1;
+        if (backward && (!s.d_out || (reinterpret_cast<uintptr_t>(s.d_out) & 15u) || (reinterpret_cast<uintptr_t>(s.d_matrix_t) & 15u))) return 1;
+        mc = s.count > mc ? s.count : mc;
+    }
+    *max_count = mc;
+    return 0;
+}
+
+int launch_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, hipStream_t st) {
+    int mc;
+    if (!frame || resfield_check(n_jobs, jobs, false, &mc)) return 1;
+    ResFieldK P;
+    for (int j = 0; j < n_jobs; ++j) P.job[j] = jobs[j];
+    P.frame = frame; P.part = nullptr; P.blocks_per_job = (mc + kRfPerBlock - 1) / kRfPerBlock;
+    hipLaunchKernelGGL(k_resfield_compose, dim3(P.blocks_per_job, n_jobs), dim3(kBlock), 0, st, P);
+    return 0;
+}
+
+size_t resfield_backward_workspace(int n_jobs, const SrResFieldJob* jobs) {
+    int mc;
+    if (resfield_check(n_jobs, jobs, true, &mc)) return 0;
+    return (size_t)n_jobs * ((mc + kRfPerBlock - 1) / kRfPerBlock) * SR_RESFIELD_MAX_RANK * sizeof(float);
+}
+
+int launch_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    int mc;
+    if (!frame || !workspace || resfield_check(n_jobs, jobs, true, &mc)) return 1;
+    if (workspace_bytes < resfield_backward_workspace(n_jobs, jobs)) return 1;
+    ResFieldK P;
+    for (int j = 0; j < n_jobs; ++j) P.job[j] = jobs[j];
+    P.frame = frame; P.part = static_cast<float*>(workspace); P.blocks_per_job = (mc + kRfPerBlock - 1) / kRfPerBlock;
+    hipLaunchKernelGGL(k_resfield_backward, dim3(P.blocks_per_job, n_jobs), dim3(kBlock), 0, st, P);
+    hipLaunchKernelGGL(k_resfield_finish, dim3(n_jobs), dim3(kBlock), 0, st, P);
+    return 0;
+}
+
+}  // namespace sr

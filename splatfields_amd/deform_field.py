@@ -5,11 +5,15 @@ Same constructor keywords, same `forward(xyz_in, t)` -> dict(scales, opacity, ro
 parameter names (`mlp_deform.net.<i>...`, `mlp_refine_feat.<i>...`, `mlp_flow_head.branch_w...`, `encoder....`), so
 `deform.pth` checkpoints (reference scene/deform_model.py:36-47) load with `load_state_dict`.
 
-What is NOT here is the tri-plane feature encoder (reference scene/tripFields.py: a diffusers / mmgen VAE decoder that
-produces the planes; those packages exist neither in the reference checkout nor in this image): pass any module with
-the encoder's interface -- `encoder(x[None]) -> [1, N, out_dim]`, attribute `out_dim` -- e.g. the reference's own
-`VarTriPlaneEncoder` instance; with `encoder=None` the network runs without plane features, which is the reference's
-behaviour for an `encoder_type` outside its list (`feat_dim = 0`, utils/time_utils.py:333-334).
+The tri-plane feature encoder (reference scene/tripFields.py:383-436) is `splatfields_amd.triplane.TriPlaneSampler`: the
+per-point lookup (three `grid_sample`s + cat) runs on HIP kernels, forward and backward.  With the reference's default
+`encoder_type='VarTriPlaneEncoder'` and no `encoder=` argument the sampler owns its planes [3, out_ch, 16 noise_res,
+16 noise_res] as a learnable parameter (a decoder-free tri-plane).  The reference GENERATES the planes with a diffusers / mmgen
+VAE decoder (`Tensorial2D`, :176-204; those packages exist neither in its checkout nor in this image): pass such a generator
+as `TriPlaneSampler(plane_source=...)`, or any module with the encoder's interface (`encoder(x[None]) -> [1, N, out_dim]`,
+attribute `out_dim`, e.g. the reference's own `VarTriPlaneEncoder` instance) as `encoder=`.  An `encoder_type` outside the
+reference's list runs without plane features (`feat_dim = 0`, utils/time_utils.py:333-334).  State-dict keys of the
+decoder-free sampler are `encoder.planes`; a reference checkpoint's `encoder.subs.*` keys need the reference's generator.
 
 `FlowHead` (utils/time_utils.py:194-303): 'offset', 'se3' (default) and 'dct'; the SE(3) exponential is written out per point
 (no 4x4 batched matmuls), following the reference's formulas including its `w / theta + 1e-5` convention.
@@ -43,8 +47,8 @@ def se3_transform(w: torch.Tensor, v: torch.Tensor, theta: torch.Tensor):
     wv = _cross(w, v)
     wwv = _cross(w, wv)
     p = theta * v + (1.0 - c) * wv + (theta - s) * wwv
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=w.device, dtype=w.dtype).expand(n, 1, 4)
-    return torch.cat([torch.cat([R, p[:, :, None]], dim=-1), bottom], dim=1)
+    bottom = torch.cat([torch.zeros(n, 1, 3, device=w.device, dtype=w.dtype), torch.ones(n, 1, 1, device=w.device, dtype=w.dtype)], dim=-1)
+    return torch.cat([torch.cat([R, p[:, :, None]], dim=-1), bottom], dim=1)   # (no host -> device copy: safe under graph capture)
 
 
 def dct_basis(num_basis: int, num_frames: int) -> torch.Tensor:
@@ -95,13 +99,15 @@ class SplatFields(nn.Module):
         rank = kwargs.get("composition_rank", 0)
         self.n_frames = n_frames
         self.encoder_type = kwargs.get("encoder_type", "VarTriPlaneEncoder")
+        if encoder is None and self.encoder_type in ["VarTriPlaneEncoder"]:
+            from .triplane import TriPlaneSampler
+            ea = kwargs.get("encoder_args", {}) or {}
+            encoder = TriPlaneSampler(out_ch=ea.get("out_ch", 16), resolution=16 * ea.get("noise_res", 20),
+                                      fuse_mode=ea.get("fuse_mode", "cat"), plane_source=ea.get("plane_source"))
         if encoder is not None:
             self.encoder = encoder
             self.feat_dim = int(encoder.out_dim)
             self.mlp_refine_feat = nn.Sequential(nn.Linear(self.feat_dim, self.feat_dim), nn.ReLU(), nn.Linear(self.feat_dim, self.feat_dim))
-        elif self.encoder_type in ["VarTriPlaneEncoder"]:
-            raise NotImplementedError("the tri-plane encoder (reference scene/tripFields.py, a diffusers / mmgen decoder) is not part of "
-                                      "this library: pass it as `encoder=` or choose another encoder_type to run without plane features")
         else:
             self.feat_dim = 0
         if n_frames > 0:

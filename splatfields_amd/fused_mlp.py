@@ -14,6 +14,7 @@ module-style wrapper.  No CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -67,16 +68,25 @@ class _Shape:
         # input-gradient ops write <= ht tiles each
         self.input_groups = [(g, min(self.ht, self.mem_pad // 16 - g)) for g in range(0, self.mem_pad // 16, self.ht)
                              if self.d_in - 16 * g > 0]
+        self.layer_dims = [tuple(W.shape) for W in weights]
+        self.plans: dict = {}     # descriptor arrays of the forward / backward / weight-gradient launches, built on first use
 
 
-class _Builder:
-    """Collects pack jobs (one device launch) and the op list that uses their outputs."""
+_PACK_PTRS, _OP_PTRS = ("w", "bias_src"), ("src", "mask", "store")
 
-    def __init__(self, device):
-        self.device = device
+
+class _Plan:
+    """One pack launch + one chain launch of a fixed shape, with the ctypes descriptor arrays built ONCE: everything static
+    (tile counts, strides, epilogues) is filled in when the plan is made; pointer fields are symbolic -- ("W", j, byte offset)
+    = weights[j].data_ptr() + offset -- and are patched per call (building ~40 descriptor structs per network and step in
+    Python cost ~0.6 ms of host time per network; patching ~60 pointers costs a few tens of microseconds)."""
+
+    def __init__(self):
         self.jobs: List[dict] = []
-        self.sizes: List[Tuple[int, int]] = []
         self.ops: List[dict] = []
+        self.sizes: List[Tuple[int, int]] = []
+        self._arrays = None
+        self._lock = threading.Lock()
 
     def add(self, job: dict, op: dict, with_bias: bool):
         floats = 16 * job["out_tiles"] * (job["mem_pad"] + job["reg_width"])
@@ -84,30 +94,69 @@ class _Builder:
         self.sizes.append((floats, 16 * job["out_tiles"] if with_bias else 0))
         self.ops.append(op)
 
-    def run(self, lib, n_points: int, ht: int, slope: float, stream) -> torch.Tensor:
+    def _freeze(self):
         if len(self.jobs) > _lib.MLP_MAX_PACK_JOBS or len(self.ops) > _lib.MLP_MAX_OPS:
             raise ValueError("network too deep for one fused chain")
-        total = sum(a + b for a, b in self.sizes)
-        buf = torch.empty(total, dtype=torch.float32, device=self.device)
-        base, at = buf.data_ptr(), 0
-        jobs = (_lib.SrMlpPackJob * len(self.jobs))()
-        ops = (_lib.SrMlpOp * len(self.ops))()
+        n = len(self.jobs)
+        jobs = (_lib.SrMlpPackJob * n)()
+        ops = (_lib.SrMlpOp * n)()
+        binds, at = [], 0     # (struct, field, symbol, index, byte offset)
         for j, (job, op, (wf, bf)) in enumerate(zip(self.jobs, self.ops, self.sizes)):
-            w_at = base + 4 * at
-            b_at = base + 4 * (at + wf) if bf else None
+            J, O = jobs[j], ops[j]
+            J.ld, J.transposed, J.row0, J.n_rows = job["ld"], job["transposed"], job["row0"], job["n_rows"]
+            J.n_mem, J.mem_pad, J.mem_col0 = job["n_mem"], job["mem_pad"], 0
+            J.n_reg, J.reg_width, J.reg_col0 = job["n_reg"], job["reg_width"], job["reg_col0"]
+            J.out_tiles, J.n_bias = job["out_tiles"], job.get("n_bias", 0)
+            O.out_tiles, O.mem_tiles, O.reg_tiles = job["out_tiles"], job["mem_pad"] // 16, job["reg_width"] // 16
+            O.src_row, O.epilogue, O.mask_row = op.get("src_row", 0), op["epilogue"], op.get("mask_row", 0)
+            O.store_row, O.store_channels = op.get("store_row", 0), op.get("store_channels", 0)
+            O.store_accumulate, O.keep_state = op.get("store_accumulate", 0), op.get("keep_state", 0)
+            binds.append((J, "dst", "buf", 0, 4 * at)); binds.append((O, "w_packed", "buf", 0, 4 * at))
+            if bf:
+                binds.append((J, "bias_dst", "buf", 0, 4 * (at + wf))); binds.append((O, "bias", "buf", 0, 4 * (at + wf)))
             at += wf + bf
-            jobs[j] = _lib.SrMlpPackJob(w=job["w"], bias_src=job.get("bias"), dst=w_at, bias_dst=b_at, ld=job["ld"],
-                                        transposed=job["transposed"], row0=job["row0"], n_rows=job["n_rows"], n_mem=job["n_mem"],
-                                        mem_pad=job["mem_pad"], mem_col0=0, n_reg=job["n_reg"], reg_width=job["reg_width"],
-                                        reg_col0=job["reg_col0"], out_tiles=job["out_tiles"], n_bias=job.get("n_bias", 0))
-            ops[j] = _lib.SrMlpOp(w_packed=w_at, bias=b_at, src=op.get("src"), mask=op.get("mask"), store=op.get("store"),
-                                  out_tiles=job["out_tiles"], mem_tiles=job["mem_pad"] // 16, reg_tiles=job["reg_width"] // 16,
-                                  src_row=op.get("src_row", 0), epilogue=op["epilogue"], mask_row=op.get("mask_row", 0),
-                                  store_row=op.get("store_row", 0), store_channels=op.get("store_channels", 0),
-                                  store_accumulate=op.get("store_accumulate", 0), keep_state=op.get("keep_state", 0))
-        _lib.check(lib.sr_mlp_pack(len(self.jobs), jobs, C.c_void_p(stream)))
-        _lib.check(lib.sr_mlp_chain(n_points, ht, len(self.ops), ops, slope, C.c_void_p(stream)))
+            for f, key in (("w", "w"), ("bias_src", "bias")):
+                if job.get(key) is not None:
+                    binds.append((J, f) + tuple(job[key]))
+            for f in _OP_PTRS:
+                if op.get(f) is not None:
+                    binds.append((O, f) + tuple(op[f]))
+        self._arrays = (jobs, ops, binds, at)
+
+    def run(self, lib, ptrs: dict, device, n_points: int, ht: int, slope: float, stream) -> torch.Tensor:
+        with self._lock:      # the descriptor arrays are shared by every call with this shape
+            if self._arrays is None:
+                self._freeze()
+            jobs, ops, binds, total = self._arrays
+            buf = torch.empty(total, dtype=torch.float32, device=device)
+            ptrs = dict(ptrs, buf=(buf.data_ptr(),))
+            for obj, field, sym, idx, off in binds:
+                setattr(obj, field, ptrs[sym][idx] + off)
+            _lib.check(lib.sr_mlp_pack(len(jobs), jobs, C.c_void_p(stream)))
+            _lib.check(lib.sr_mlp_chain(n_points, ht, len(ops), ops, slope, C.c_void_p(stream)))
         return buf      # alive until the caller drops it; the stream orders its reuse
+
+
+def _forward_plan(shape: _Shape, save: bool) -> _Plan:
+    key = ("fwd", save)
+    if key not in shape.plans:
+        H, L = shape.hidden, shape.n_layers
+        b = _Plan()
+        for j in range(L):
+            last = j == L - 1
+            rows, cols = shape.layer_dims[j]
+            n_mem = shape.d_in if shape.reads_input[j] else 0
+            job = dict(w=("W", j, 0), ld=cols, transposed=0, row0=0, n_rows=rows, n_mem=n_mem,
+                       mem_pad=shape.mem_pad if n_mem else 0, n_reg=cols - n_mem, reg_width=0 if j == 0 else H, reg_col0=n_mem,
+                       out_tiles=shape.out_tiles_last if last else shape.ht, bias=("B", j, 0), n_bias=rows)
+            op = dict(epilogue=_lib.MLP_LEAKY, src=("x0", 0, 0) if n_mem else None, src_row=shape.mem_pad)
+            if last:
+                op.update(store=("y", 0, 0), store_row=shape.out_features, store_channels=shape.out_features)
+            elif save:
+                op.update(store=("acts", j, 0), store_row=H, store_channels=H)
+            b.add(job, op, with_bias=True)
+        shape.plans[key] = b
+    return shape.plans[key]
 
 
 def _forward(shape: _Shape, x0: torch.Tensor, weights, biases, slope: float, save: bool):
@@ -116,22 +165,40 @@ def _forward(shape: _Shape, x0: torch.Tensor, weights, biases, slope: float, sav
     dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
     y = torch.empty(n, shape.out_features, dtype=torch.float32, device=dev)
     acts = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev) if save else None
-    b = _Builder(dev)
-    for j, (W, bias) in enumerate(zip(weights, biases)):
-        last = j == L - 1
-        n_mem = shape.d_in if shape.reads_input[j] else 0
-        job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=0, row0=0, n_rows=W.shape[0], n_mem=n_mem,
-                   mem_pad=shape.mem_pad if n_mem else 0, n_reg=W.shape[1] - n_mem, reg_width=0 if j == 0 else H, reg_col0=n_mem,
-                   out_tiles=shape.out_tiles_last if last else shape.ht, bias=bias.data_ptr(), n_bias=bias.shape[0])
-        op = dict(epilogue=_lib.MLP_LEAKY, src=x0.data_ptr() if n_mem else None, src_row=shape.mem_pad)
-        if last:
-            op.update(store=y.data_ptr(), store_row=shape.out_features, store_channels=shape.out_features)
-        elif save:
-            op.update(store=acts[j].data_ptr(), store_row=H, store_channels=H)
-        b.add(job, op, with_bias=True)
+    ptrs = {"W": [w.data_ptr() for w in weights], "B": [b_.data_ptr() for b_ in biases], "x0": (x0.data_ptr(),), "y": (y.data_ptr(),),
+            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)] if save else ()}
     with torch.cuda.device(dev):
-        b.run(lib, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
+        _forward_plan(shape, save).run(lib, ptrs, dev, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
     return y, acts
+
+
+def _backward_plan(shape: _Shape, need_input: bool) -> _Plan:
+    key = ("bwd", need_input)
+    if key not in shape.plans:
+        H, L = shape.hidden, shape.n_layers
+        b = _Plan()
+        for j in range(L - 1, -1, -1):
+            ld = shape.layer_dims[j][1]
+            top = j == L - 1
+            n_mem_w = shape.d_in if shape.reads_input[j] else 0        # columns of W_j that multiply the network input
+            # this layer's dZ is the op input: memory (G) for the top layer, the register state below it
+            cols = dict(n_mem=shape.out_features, mem_pad=shape.out_pad, n_reg=0, reg_width=0, reg_col0=0) if top else \
+                dict(n_mem=0, mem_pad=0, n_reg=H, reg_width=H, reg_col0=0)
+            src = dict(src=("G", 0, 0), src_row=shape.out_pad) if top else {}
+            if need_input and n_mem_w:
+                for g0, cnt in shape.input_groups:                      # dL/dx0 += W_j[:, input block]^T dZ_j, <= ht tiles at a time
+                    rows = min(16 * cnt, shape.d_in - 16 * g0)
+                    job = dict(w=("W", j, 0), ld=ld, transposed=1, row0=16 * g0, n_rows=rows, out_tiles=cnt, **cols)
+                    op = dict(epilogue=_lib.MLP_NONE, keep_state=1, store=("dx0", 0, 4 * 16 * g0), store_row=shape.mem_pad,
+                              store_channels=rows, store_accumulate=1, **src)
+                    b.add(job, op, with_bias=False)
+            if j > 0:                                                   # dZ_{j-1} = (W_j[:, hidden block]^T dZ_j) * act'(h_{j-1})
+                job = dict(w=("W", j, 0), ld=ld, transposed=1, row0=n_mem_w, n_rows=H, out_tiles=shape.ht, **cols)
+                op = dict(epilogue=_lib.MLP_MASK, mask=("acts", j - 1, 0), mask_row=H, store=("dz", j - 1, 0), store_row=H,
+                          store_channels=H, **src)
+                b.add(job, op, with_bias=False)
+        shape.plans[key] = b
+    return shape.plans[key]
 
 
 def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input: bool):
@@ -142,74 +209,87 @@ def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input:
     G = F.pad(gz, (0, shape.out_pad - shape.out_features)).contiguous()
     dz = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev)
     dx0 = torch.zeros(n, shape.mem_pad, dtype=torch.float32, device=dev) if need_input else None
-    b = _Builder(dev)
-    for j in range(L - 1, -1, -1):
-        W = weights[j]
-        top = j == L - 1
-        n_mem_w = shape.d_in if shape.reads_input[j] else 0        # columns of W_j that multiply the network input
-        # this layer's dZ is the op input: memory (G) for the top layer, the register state below it
-        cols = dict(n_mem=shape.out_features, mem_pad=shape.out_pad, n_reg=0, reg_width=0, reg_col0=0) if top else \
-            dict(n_mem=0, mem_pad=0, n_reg=H, reg_width=H, reg_col0=0)
-        src = dict(src=G.data_ptr(), src_row=shape.out_pad) if top else {}
-        if need_input and n_mem_w:
-            for g0, cnt in shape.input_groups:                      # dL/dx0 += W_j[:, input block]^T dZ_j, <= ht tiles at a time
-                rows = min(16 * cnt, shape.d_in - 16 * g0)
-                job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=1, row0=16 * g0, n_rows=rows, out_tiles=cnt, **cols)
-                op = dict(epilogue=_lib.MLP_NONE, keep_state=1, store=dx0.data_ptr() + 4 * 16 * g0, store_row=shape.mem_pad,
-                          store_channels=rows, store_accumulate=1, **src)
-                b.add(job, op, with_bias=False)
-        if j > 0:                                                   # dZ_{j-1} = (W_j[:, hidden block]^T dZ_j) * act'(h_{j-1})
-            job = dict(w=W.data_ptr(), ld=W.stride(0), transposed=1, row0=n_mem_w, n_rows=H, out_tiles=shape.ht, **cols)
-            op = dict(epilogue=_lib.MLP_MASK, mask=acts[j - 1].data_ptr(), mask_row=H, store=dz[j - 1].data_ptr(), store_row=H,
-                      store_channels=H, **src)
-            b.add(job, op, with_bias=False)
+    ptrs = {"W": [w.data_ptr() for w in weights], "G": (G.data_ptr(),), "dx0": (dx0.data_ptr() if need_input else 0,),
+            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)], "dz": [dz.data_ptr() + 4 * j * n * H for j in range(L - 1)]}
     with torch.cuda.device(dev):
-        b.run(lib, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
+        _backward_plan(shape, need_input).run(lib, ptrs, dev, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
     return dx0, G, dz
 
 
+def _grad_jobs(shape: _Shape):
+    """static part of the weight-gradient job list: (layer, dz symbol, dz_row, m, x symbol, x_row, k, dw_row, dw_col0, first)"""
+    if "grad" not in shape.plans:
+        H, L, out = shape.hidden, shape.n_layers, []
+        for j in range(L):
+            top = j == L - 1
+            dz_sym, dz_row, m = (("G", 0), shape.out_pad, shape.out_features) if top else (("dz", j), H, H)
+            col0, first = 0, True
+            segments = []
+            if shape.reads_input[j]:
+                segments.append((("x0", 0), shape.mem_pad, shape.d_in))
+            if j > 0:
+                segments.append((("acts", j - 1), H, H))
+            for x_sym, x_row, k in segments:
+                out.append((j, dz_sym, dz_row, m, x_sym, x_row, k, shape.layer_dims[j][1], col0, first))
+                col0 += k
+                first = False
+        if len(out) > _lib.MLP_MAX_GRAD_JOBS:
+            raise ValueError("network too deep for one weight-gradient launch")
+        arr = (_lib.SrMlpGradJob * len(out))()
+        for i, (j, _, dz_row, m, _, x_row, k, dw_row, col0, _) in enumerate(out):
+            arr[i].dz_row, arr[i].m, arr[i].x_row, arr[i].k, arr[i].dw_row, arr[i].dw_col0 = dz_row, m, x_row, k, dw_row, col0
+        shape.plans["grad"] = (out, arr, threading.Lock())
+    return shape.plans["grad"]
+
+
 def _weight_grads(shape: _Shape, x0, acts, G, dz, weights):
-    """dW_j = dZ_j^T [h_in | h_{j-1}], db_j = sum over points of dZ_j, all layers in one launch (sr_mlp_weight_grad)."""
+    """dW_j = dZ_j^T [h_in | h_{j-1}], db_j = sum over points of dZ_j, all layers in one launch (sr_mlp_weight_grad).  The kernel
+    addresses its operands with 32-bit byte offsets: larger point sets are cut into chunks whose partial gradients are added
+    (a reference-sized network reaches that limit at ~2.4 M points)."""
     lib = _lib.load()
     dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
-    dWs = [torch.empty_like(W) for W in weights]
-    dbs = [torch.empty(W.shape[0], dtype=torch.float32, device=dev) for W in weights]
-    jobs = []
-    for j in range(L):
-        top = j == L - 1
-        dzj, dz_row, m = (G, shape.out_pad, shape.out_features) if top else (dz[j], H, H)
-        col0, first = 0, True
-        segments = []
-        if shape.reads_input[j]:
-            segments.append((x0, shape.mem_pad, shape.d_in))
-        if j > 0:
-            segments.append((acts[j - 1], H, H))
-        for x, x_row, k in segments:
-            jobs.append(_lib.SrMlpGradJob(dz=dzj.data_ptr(), x=x.data_ptr(), dw=dWs[j].data_ptr(), db=dbs[j].data_ptr() if first else None,
-                                          dz_row=dz_row, m=m, x_row=x_row, k=k, dw_row=dWs[j].shape[1], dw_col0=col0))
-            col0 += k
-            first = False
-    if len(jobs) > _lib.MLP_MAX_GRAD_JOBS:
-        raise ValueError("network too deep for one weight-gradient launch")
-    arr = (_lib.SrMlpGradJob * len(jobs))(*jobs)
-    ws_bytes = lib.sr_mlp_weight_grad_workspace(n, len(jobs), arr)
-    if ws_bytes == 0:
-        raise ValueError("unsupported weight-gradient job list: " + lib.sr_last_error().decode("utf-8", "replace"))
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.sr_mlp_weight_grad(n, len(jobs), arr, C.c_void_p(ws.data_ptr()), ws_bytes,
-                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    return dWs, dbs
+    jobs, arr, lock = _grad_jobs(shape)
+    row_bytes = 4 * max(shape.mem_pad, shape.out_pad, H)
+    n_max = max(64, ((1 << 31) - 1) // row_bytes // 64 * 64)
+    total_W, total_b = None, None
+    for lo in range(0, n, n_max):
+        cnt = min(n_max, n - lo)
+        dWs = [torch.empty_like(W) for W in weights]
+        dbs = [torch.empty(W.shape[0], dtype=torch.float32, device=dev) for W in weights]
+        base = {"G": (G.data_ptr() + 4 * lo * shape.out_pad,), "x0": (x0.data_ptr() + 4 * lo * shape.mem_pad,),
+                "dz": [dz.data_ptr() + 4 * (j * n + lo) * H for j in range(L - 1)],
+                "acts": [acts.data_ptr() + 4 * (j * n + lo) * H for j in range(L - 1)]}
+        with lock:
+            for i, (j, dz_sym, _, _, x_sym, _, _, _, _, first) in enumerate(jobs):
+                arr[i].dz, arr[i].x = base[dz_sym[0]][dz_sym[1]], base[x_sym[0]][x_sym[1]]
+                arr[i].dw, arr[i].db = dWs[j].data_ptr(), (dbs[j].data_ptr() if first else None)
+            ws_bytes = lib.sr_mlp_weight_grad_workspace(cnt, len(jobs), arr)
+            if ws_bytes == 0:
+                raise ValueError("unsupported weight-gradient job list: " + lib.sr_last_error().decode("utf-8", "replace"))
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sr_mlp_weight_grad(cnt, len(jobs), arr, C.c_void_p(ws.data_ptr()), ws_bytes,
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if total_W is None:
+            total_W, total_b = dWs, dbs
+        else:      # fixed chunk order: still deterministic
+            for a_, b_ in zip(total_W, dWs):
+                a_.add_(b_)
+            for a_, b_ in zip(total_b, dbs):
+                a_.add_(b_)
+    return total_W, total_b
 
 
 class _FusedMLPFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h_in, shape: _Shape, slope: float, *params):
+    def forward(ctx, h_in, shape: _Shape, slope: float, grad_enabled: bool, *params):
         L = shape.n_layers
         weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
         biases = [p.detach().to(torch.float32).contiguous() for p in params[L:]]
         x0 = F.pad(h_in.detach().to(torch.float32), (0, shape.mem_pad - shape.d_in)).contiguous()
-        need = any(ctx.needs_input_grad)
+        # needs_input_grad reflects requires_grad of the inputs, not the grad mode (inside forward() grad mode is always off):
+        # under torch.no_grad() nothing will run backward, so the [L-1, N, hidden] activation stack is neither allocated nor written
+        need = grad_enabled and any(ctx.needs_input_grad)
         y, acts = _forward(shape, x0, weights, biases, slope, save=need)
         if need:
             ctx.shape, ctx.slope = shape, slope
@@ -225,11 +305,11 @@ class _FusedMLPFn(torch.autograd.Function):
         need_input = ctx.needs_input_grad[0]
         dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_input)
         dWs, dbs = [None] * L, [None] * L
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dWs, dbs = _weight_grads(shape, x0, acts, G, dz, weights)
-            dWs = [g if ctx.needs_input_grad[3 + j] else None for j, g in enumerate(dWs)]
-            dbs = [g if ctx.needs_input_grad[3 + L + j] else None for j, g in enumerate(dbs)]
-        return (dx0[:, :d_in] if need_input else None, None, None, *dWs, *dbs)
+            dWs = [g if ctx.needs_input_grad[4 + j] else None for j, g in enumerate(dWs)]
+            dbs = [g if ctx.needs_input_grad[4 + L + j] else None for j, g in enumerate(dbs)]
+        return (dx0[:, :d_in] if need_input else None, None, None, None, *dWs, *dbs)
 
 
 def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], skips: Sequence[int] = (),
@@ -257,7 +337,7 @@ def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biase
         raise ValueError("h_in must be float32 (the reference network runs in fp32)")
     if h_in.shape[0] == 0:      # nothing to launch; keep the graph connected so that parameters still receive (zero) gradients
         return h_in.new_zeros(0, shape.out_features) + 0.0 * (h_in.sum() + sum(w.sum() for w in weights) + sum(b.sum() for b in biases))
-    return _FusedMLPFn.apply(h_in, shape, float(negative_slope), *weights, *biases)
+    return _FusedMLPFn.apply(h_in, shape, float(negative_slope), torch.is_grad_enabled(), *weights, *biases)
 
 
 class FusedGeneralMLP:

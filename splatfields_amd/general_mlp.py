@@ -10,20 +10,23 @@ GeneralMLP builds: compression 'vm', mode 'lookup', fuse 'add') `net.<i>.weights
   (splatfields_amd/fused_mlp.py);
 * a ResField layer composes ONLY the current frame's weight, `W + (weights_t[frame_id] @ matrix_t).view_as(W)`; the
   reference builds the [capacity, out * in] matrix of all frames on every call and indexes it
-  (utils/resfields.py:229,294-300) -- same values, 1/capacity of the work; autograd carries dL/dW_effective on to `weight`,
-  `weights_t[frame_id]` and `matrix_t`.
+  (utils/resfields.py:229,294-300) -- same values, 1/capacity of the work.  All ResField layers of the network are composed
+  by ONE kernel launch (`compose_resfield_weights`, csrc/mlp.hip: sr_resfield_compose) and their `weights_t` / `matrix_t`
+  gradients come from one more pair of launches, instead of ~8 small PyTorch kernels per layer and step.
 
 Supported: the configurations `SplatFields` constructs (utils/time_utils.py:343-447) -- act 'leaky_relu' (or 'relu'), hidden width 64 or
 128, any out_activation of the reference's table.  Anything else raises; there is no PyTorch-layer or CPU path.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional, Sequence
 
 import torch
 from torch import nn
 
+from . import _lib
 from .fused_mlp import _Shape, fused_general_mlp
 
 
@@ -67,6 +70,83 @@ class ResFieldLinear(nn.Module):
             raise ValueError("a ResField layer needs frame_id")
         coeff = self.weights_t[frame_id].reshape(1, self.rank)            # frame_id: int or 0-dim tensor (no host sync)
         return self.weight + (coeff @ self.matrix_t).view_as(self.weight)
+
+
+class _ResFieldCompose(torch.autograd.Function):
+    """W_eff of the current frame for ALL ResField layers of a network: one launch forward, two backward
+    (include/splatraster.h: sr_resfield_compose / sr_resfield_backward).  Inputs: frame [] int64 on the device, then
+    (weight, weights_t, matrix_t) per layer; outputs: one composed weight per layer."""
+
+    @staticmethod
+    def forward(ctx, frame: torch.Tensor, *params):
+        lib = _lib.load()
+        n = len(params) // 3
+        if n < 1 or n > _lib.RESFIELD_MAX_JOBS:
+            raise ValueError("between 1 and %d ResField layers per call" % _lib.RESFIELD_MAX_JOBS)
+        dev = params[0].device
+        Ws = [p.detach().contiguous() for p in params[0::3]]
+        wts = [p.detach().contiguous() for p in params[1::3]]
+        Ms = [p.detach().contiguous() for p in params[2::3]]
+        frame = frame.detach().to(device=dev, dtype=torch.int64).reshape(1).contiguous()
+        outs = [torch.empty_like(W) for W in Ws]
+        jobs = (_lib.SrResFieldJob * n)()
+        for j in range(n):
+            jobs[j].w, jobs[j].weights_t, jobs[j].matrix_t, jobs[j].out = Ws[j].data_ptr(), wts[j].data_ptr(), Ms[j].data_ptr(), outs[j].data_ptr()
+            jobs[j].count, jobs[j].rank, jobs[j].capacity = Ws[j].numel(), wts[j].shape[1], wts[j].shape[0]
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_resfield_compose(n, jobs, C.c_void_p(frame.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.save_for_backward(frame, *wts, *Ms)
+        ctx.n = n
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        lib = _lib.load()
+        n = ctx.n
+        frame, *rest = ctx.saved_tensors
+        wts, Ms = rest[:n], rest[n:]
+        dev = frame.device
+        gs = [(g if g is not None else torch.zeros_like(M[0]).view(-1)).contiguous() for g, M in zip(gouts, Ms)]
+        d_wts = [torch.empty_like(t) if ctx.needs_input_grad[2 + 3 * j] else None for j, t in enumerate(wts)]
+        d_Ms = [torch.empty_like(t) if ctx.needs_input_grad[3 + 3 * j] else None for j, t in enumerate(Ms)]
+        jobs = (_lib.SrResFieldJob * n)()
+        for j in range(n):
+            jobs[j].weights_t, jobs[j].matrix_t, jobs[j].d_out = wts[j].data_ptr(), Ms[j].data_ptr(), gs[j].data_ptr()
+            jobs[j].d_matrix_t = d_Ms[j].data_ptr() if d_Ms[j] is not None else None
+            jobs[j].d_weights_t = d_wts[j].data_ptr() if d_wts[j] is not None else None
+            jobs[j].count, jobs[j].rank, jobs[j].capacity = Ms[j].shape[1], wts[j].shape[1], wts[j].shape[0]
+        ws_bytes = lib.sr_resfield_backward_workspace(n, jobs)
+        if ws_bytes == 0:
+            raise ValueError("unsupported ResField job list")
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_resfield_backward(n, jobs, C.c_void_p(frame.data_ptr()), C.c_void_p(ws.data_ptr()), ws_bytes,
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        grads = [None]
+        for j in range(n):       # dL/dW is dL/dW_eff itself
+            grads += [gouts[j] if ctx.needs_input_grad[1 + 3 * j] else None, d_wts[j], d_Ms[j]]
+        return tuple(grads)
+
+
+def compose_resfield_weights(layers: Sequence["ResFieldLinear"], frame_id) -> list:
+    """effective weights of all `layers` at `frame_id` (plain weights for layers without a residual): the residual layers are
+    composed together by the fused kernel when they live on a HIP device, by `ResFieldLinear.effective` otherwise."""
+    res = [l for l in layers if l.has_residual]
+    if not res:
+        return [l.weight for l in layers]
+    if frame_id is None:
+        raise ValueError("a ResField layer needs frame_id")
+    fusable = all(l.weight.is_cuda and l.weight.dtype == torch.float32 and l.weight.numel() % 4 == 0 and l.rank <= _lib.RESFIELD_MAX_RANK
+                  for l in res) and len(res) <= _lib.RESFIELD_MAX_JOBS
+    if not fusable:
+        return [l.effective(frame_id) for l in layers]
+    frame = frame_id if torch.is_tensor(frame_id) else torch.tensor(int(frame_id), dtype=torch.int64, device=res[0].weight.device)
+    flat = []
+    for l in res:
+        flat += [l.weight, l.weights_t, l.matrix_t]
+    composed = iter(_ResFieldCompose.apply(frame, *flat))
+    return [next(composed) if l.has_residual else l.weight for l in layers]
 
 
 _OUT_ACTIVATIONS = {
@@ -121,7 +201,7 @@ class GeneralMLP(nn.Module):
         h_in = positional_encoding(xyz, self.multires)
         if xyz_feat is not None:
             h_in = torch.cat([h_in, xyz_feat], dim=-1)
-        weights = [layer.effective(frame_id) for layer in self.net]
+        weights = compose_resfield_weights(list(self.net), frame_id)
         biases = [layer.bias for layer in self.net]
         h = fused_general_mlp(h_in, weights, biases, skips=self.skips, negative_slope=self.slope, _shape=self._static_shape())
         return self.out_act(h)

@@ -17,6 +17,13 @@ reference checkout exists at /root/reference; the fixtures (pure numbers) are wh
                       and the gradients of sum(output * probe) w.r.t. the inputs and every parameter, for the shapes
                       SplatFields builds (scaled down).  scene.tripFields (diffusers / mmgen, absent here) is not needed by
                       GeneralMLP and is kept out of the import.
+  densify_*.npz    -- the reference's own GaussianModel.densify_and_prune (scene/gaussian_model.py:411-425, with the clone /
+                      split / prune and optimizer surgery of :272-409) run on CPU on small clouds after one Adam step:
+                      the state before (parameters, Adam moments, statistics), the thresholds, the unit normal samples its
+                      torch.normal call drew (recorded, with the split mask its prune_points call received), and the state after.
+  triplane_*.npz   -- the reference's own VarTriPlaneEncoder.forward (scene/tripFields.py:430-436: grid_sample of the three planes +
+                      cat) with stand-in plane generators (its TimeVAEDecoder needs diffusers / mmgen): planes, points (some
+                      outside [-1, 1]), features, and the gradients of sum(features * probe) w.r.t. planes and points.
   splatfields_*.npz -- the reference's whole SplatFields network (utils/time_utils.py:305-508: six GeneralMLPs, time embedding,
                       FlowHead) in configurations without plane features, same contents as above for every output of
                       forward(xyz, t).
@@ -330,8 +337,167 @@ def splatfields_cases():
         print(name, sorted(k for k in data if k.startswith("out:")), sum(v.size for v in data.values()), "floats")
 
 
+def densify_cases():
+    """Runs the reference's GaussianModel.densify_and_prune itself.  Only device literals are patched (torch.zeros(...,
+    device="cuda") -> CPU); torch.normal and prune_points are WRAPPED to record what the reference drew / decided, nothing of
+    its logic is restated here."""
+    import_reference()
+    orig_zeros, orig_normal, orig_empty_cache = torch.zeros, torch.normal, torch.cuda.empty_cache
+
+    def zeros_cpu(*a, **k):
+        k.pop("device", None)
+        return orig_zeros(*a, **k)
+
+    torch.zeros = zeros_cpu
+    torch.cuda.empty_cache = lambda: None
+    try:
+        # scene/__init__.py pulls in the whole training stack (deform model, decoders); only the module itself is wanted
+        saved_scene = sys.modules.get("scene")
+        pkg = types.ModuleType("scene")
+        pkg.__path__ = [os.path.join(REF, "scene")]
+        sys.modules["scene"] = pkg
+        try:
+            from scene.gaussian_model import GaussianModel
+        finally:
+            if saved_scene is None:
+                sys.modules.pop("scene", None)
+            else:
+                sys.modules["scene"] = saved_scene
+        from torch import nn
+        cases = [("aniso_screen", 900, False, 20.0, 11), ("aniso_noscreen", 900, False, None, 12), ("isotropic_screen", 700, True, 20.0, 13),
+                 ("tiny", 5, False, None, 14)]
+        for name, n, isotropic, screen, seed in cases:
+            g = torch.Generator().manual_seed(seed)
+            r = lambda *sh: torch.randn(*sh, generator=g)
+            m = GaussianModel(1)                       # sh_degree 1: f_rest [N, 3, 3] keeps the fixture small
+            m.use_isotropic = isotropic
+            m._xyz = nn.Parameter(r(n, 3))
+            m._features_dc = nn.Parameter(r(n, 1, 3))
+            m._features_rest = nn.Parameter(r(n, 3, 3) * 0.1)
+            m._opacity = nn.Parameter(r(n, 1) * 2.5)
+            m._scaling = nn.Parameter(math.log(0.03) + 1.2 * r(n, 1 if isotropic else 3))
+            m._rotation = nn.Parameter(r(n, 4))
+            args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                                         position_lr_max_steps=30000, feature_lr=2.5e-3, opacity_lr=0.05, scaling_lr=5e-3, rotation_lr=1e-3)
+            m.training_setup(args)                     # :123-143 (Adam with one named group per tensor)
+            for grp in m.optimizer.param_groups:       # one Adam step so that the moments exist and are non-trivial
+                grp["params"][0].grad = r(*grp["params"][0].shape)
+            m.optimizer.step()
+            m.xyz_gradient_accum = torch.rand(n, 1, generator=g) * 0.01
+            m.denom = torch.randint(0, 6, (n, 1), generator=g).float()
+            m.xyz_gradient_accum[m.denom == 0] = 0.0   # 0 / 0 -> NaN -> 0 inside the reference
+            m.max_radii2D = torch.rand(n, generator=g) * 40
+            names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+                     "rotation": "_rotation"}
+            data = {"max_grad": np.float32(0.0035), "min_opacity": np.float32(0.1), "extent": np.float32(4.0),
+                    "max_screen_size": np.float32(screen if screen else 0.0), "percent_dense": np.float32(m.percent_dense),
+                    "isotropic": np.int32(isotropic)}
+            for grp in m.optimizer.param_groups:
+                p_ = grp["params"][0]
+                st = m.optimizer.state[p_]
+                data["in:" + grp["name"]] = p_.detach().numpy().copy()
+                data["in_m:" + grp["name"]] = st["exp_avg"].numpy().copy()
+                data["in_v:" + grp["name"]] = st["exp_avg_sq"].numpy().copy()
+            data["in:accum"], data["in:denom"], data["in:radii"] = m.xyz_gradient_accum.numpy().copy(), m.denom.numpy().copy(), m.max_radii2D.numpy().copy()
+            drawn, masks = [], []
+
+            def normal_rec(mean=None, std=None, **k):
+                out = orig_normal(mean=mean, std=std, generator=g)
+                drawn.append((out.detach().clone(), std.detach().clone()))
+                return out
+
+            orig_prune = GaussianModel.prune_points
+
+            def prune_rec(self, mask):
+                masks.append(mask.clone())
+                return orig_prune(self, mask)
+
+            torch.normal, GaussianModel.prune_points = normal_rec, prune_rec
+            try:
+                m.densify_and_prune(0.0035, 0.1, 4.0, screen)     # the reference itself
+            finally:
+                torch.normal, GaussianModel.prune_points = orig_normal, orig_prune
+            assert len(drawn) == 1 and len(masks) == 2
+            samples, stds = drawn[0]
+            split_mask = masks[0][:n]                   # prune filter of densify_and_split = cat(selected mask, zeros): the selected splats
+            assert not masks[0][:n].numel() == 0 and int(masks[0][n:].sum()) == 0 or n == 0
+            idx = torch.nonzero(split_mask).reshape(-1)
+            unit = torch.zeros(2, n, 3)
+            S = idx.numel()
+            assert samples.shape[0] == 2 * S
+            unit[0][idx] = samples[:S] / stds[:S]       # the unit normals behind torch.normal(0, std): first and second child
+            unit[1][idx] = samples[S:] / stds[S:]
+            data["unit_normals"] = unit.numpy()
+            data["split_mask"] = split_mask.numpy()
+            for grp in m.optimizer.param_groups:
+                p_ = grp["params"][0]
+                st = m.optimizer.state[p_]
+                assert p_ is getattr(m, names[grp["name"]])
+                data["out:" + grp["name"]] = p_.detach().numpy().copy()
+                data["out_m:" + grp["name"]] = st["exp_avg"].numpy().copy()
+                data["out_v:" + grp["name"]] = st["exp_avg_sq"].numpy().copy()
+                data["step:" + grp["name"]] = np.float32(float(st["step"]))
+            data["out:accum"], data["out:denom"], data["out:radii"] = (m.xyz_gradient_accum.detach().numpy(), m.denom.detach().numpy(),
+                                                                       m.max_radii2D.detach().numpy())
+            np.savez_compressed(os.path.join(HERE, f"densify_{name}.npz"), **data)
+            print(f"densify_{name}: {n} -> {data['out:xyz'].shape[0]} rows, {S} split, {sum(v.size for v in data.values())} numbers")
+    finally:
+        torch.zeros, torch.normal, torch.cuda.empty_cache = orig_zeros, orig_normal, orig_empty_cache
+
+
+def triplane_cases():
+    """The per-point half of the reference's tri-plane encoder, run through the reference class itself.  scene/time_decoders.py
+    (diffusers / mmgen) is masked and mmgen's build_module returns a stand-in generator that hands out a fixed learnable plane;
+    VarTriPlaneEncoder.get_planes / forward (the code under test) are the reference's."""
+    from torch import nn
+    sys.path.insert(0, REF)
+
+    class StandInGenerator(nn.Module):
+        shape = (16, 24, 24)
+
+        def __init__(self):
+            super().__init__()
+            self.plane = nn.Parameter(torch.randn(1, *StandInGenerator.shape, generator=StandInGenerator.gen))
+
+        def forward(self, noise, frame_id=None):
+            return self.plane
+
+    saved = {k: sys.modules.get(k) for k in ("scene", "scene.time_decoders", "scene.tripFields", "mmgen", "mmgen.models")}
+    pkg = types.ModuleType("scene"); pkg.__path__ = [os.path.join(REF, "scene")]
+    td = types.ModuleType("scene.time_decoders"); td.TimeVAEDecoder = object
+    mm = types.ModuleType("mmgen"); mm.__path__ = []
+    mmm = types.ModuleType("mmgen.models"); mmm.build_module = lambda cfg, *a, **k: StandInGenerator()
+    sys.modules.update({"scene": pkg, "scene.time_decoders": td, "mmgen": mm, "mmgen.models": mmm})
+    sys.modules.pop("scene.tripFields", None)
+    try:
+        from scene.tripFields import VarTriPlaneEncoder
+        for name, shape, n, seed in (("c16_24x24", (16, 24, 24), 600, 21), ("c8_20x28", (8, 20, 28), 300, 22)):
+            g = torch.Generator().manual_seed(seed)
+            StandInGenerator.shape, StandInGenerator.gen = shape, g
+            enc = VarTriPlaneEncoder({"out_ch": shape[0], "noise_res": 4, "layer_kwargs": {}})
+            pts = (torch.rand(1, n, 3, generator=g) * 2.3 - 1.15).requires_grad_(True)   # ~13 % of the coordinates outside [-1, 1]
+            with torch.no_grad():
+                pts[0, 0] = torch.tensor([-1.0, 1.0, 0.0]); pts[0, 1] = torch.tensor([1.0, -1.0, 1.0])   # plane borders exactly
+            feat = enc(pts)                                                                # the reference's forward
+            probe = torch.randn(feat.shape, generator=g)
+            (feat * probe).sum().backward()
+            planes = torch.cat([sub.net.plane for sub in enc.subs], dim=0)
+            grad_planes = torch.cat([sub.net.plane.grad for sub in enc.subs], dim=0)
+            assert enc.out_dim == 3 * shape[0] and tuple(feat.shape) == (1, n, 3 * shape[0])
+            np.savez_compressed(os.path.join(HERE, f"triplane_{name}.npz"), planes=planes.detach().numpy(), pts=pts.detach().numpy(),
+                                out=feat.detach().numpy(), probe=probe.numpy(), grad_planes=grad_planes.numpy(), grad_pts=pts.grad.numpy(),
+                                axis=np.array(enc.axis))
+            print(f"triplane_{name}: planes {tuple(planes.shape)}, {n} points -> {tuple(feat.shape)}")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]          # e.g. `make_golden.py general_mlp_cases` regenerates one family
-    for fn in (ref_pieces, render_contract, tiny_scenes, general_mlp_cases, splatfields_cases):
+    for fn in (ref_pieces, render_contract, tiny_scenes, general_mlp_cases, splatfields_cases, densify_cases, triplane_cases):
         if not only or fn.__name__ in only:
             fn()

@@ -96,8 +96,10 @@ def test_se3_transform_is_a_rigid_motion_for_unit_axes():
 
 def test_encoder_contract():
     from splatfields_amd.deform_field import SplatFields
-    with pytest.raises(NotImplementedError, match="tri-plane"):
-        SplatFields(n_frames=0)                                  # the default encoder_type asks for the tri-plane encoder
+    default = SplatFields(n_frames=0, encoder_args={"noise_res": 2})   # the reference's default encoder_type: the tri-plane sampler
+    assert default.feat_dim == 48 and tuple(default.encoder.planes.shape) == (3, 16, 32, 32)
+    assert "encoder.planes" in default.state_dict() and default.mlp_deform.d_in == 3 * 13 + 48
+    assert SplatFields(n_frames=0, encoder_type="none").feat_dim == 0    # outside the reference's list: no plane features
 
     class Planes(torch.nn.Module):                               # anything with the encoder's interface can be plugged in
         out_dim = 6

@@ -36,9 +36,13 @@ def job_matrix(job):
         if job["n_reg"]: A[:nr, job["mem_pad"]:job["mem_pad"]+job["n_reg"]] = W[job["row0"]:job["row0"]+nr, job["reg_col0"]:job["reg_col0"]+job["n_reg"]]
     return A
 
-def interpret(self, lib, n, ht, slope, stream):
+def interpret(self, lib, ptrs, device, n, ht, slope, stream):
+    """stands in for _Plan.run: the plan's pointer fields are symbolic (name, index, byte offset) and are resolved here"""
+    def resolved(d, keys):
+        return {k: (ptrs[v[0]][v[1]] + v[2] if (k in keys and v is not None) else v) for k, v in d.items()}
     state = torch.zeros(n, 16 * ht)
     for job, op in zip(self.jobs, self.ops):
+        job, op = resolved(job, ("w", "bias")), resolved(op, ("src", "mask", "store"))
         A = job_matrix(job)
         mem_t, reg_t = job["mem_pad"], job["reg_width"]
         parts = []
@@ -81,7 +85,7 @@ def test_op_lists_compute_the_network_and_its_gradients(monkeypatch, d_in, H, nh
     monkeypatch.setattr(_lib, "load", lambda: None)
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
-    monkeypatch.setattr(fm._Builder, "run", interpret)
+    monkeypatch.setattr(fm._Plan, "run", interpret)
     g = torch.Generator().manual_seed(1)
     L = nh + 2
     dims_in = [d_in] + [H + (d_in if (j - 1) in skips else 0) for j in range(1, L)]

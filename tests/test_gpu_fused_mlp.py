@@ -258,3 +258,40 @@ def test_weight_grad_kernel_matches_float64_products(hip_device, n):
     for u, v in zip(got, run()):
         assert torch.equal(u, v)
     assert lib.sr_mlp_weight_grad(n, 4, jobs, C.c_void_p(ws.data_ptr()), nbytes - 16, stream) != 0     # workspace too small
+
+
+def test_resfield_composition_kernel(hip_device):
+    """All ResField layers of a network composed by one launch (sr_resfield_compose) and differentiated by sr_resfield_backward,
+    against the PyTorch statement `W + (weights_t[frame] @ matrix_t).view_as(W)` (reference utils/resfields.py:229,294-300) at the
+    reference's rank 40 / 100 frames and its layer shapes; bit-reproducible."""
+    from splatfields_amd.general_mlp import ResFieldLinear, compose_resfield_weights
+    dev = hip_device
+    torch.manual_seed(3)
+    layers = [ResFieldLinear(94, 128), ResFieldLinear(128, 128, 40, 100), ResFieldLinear(222, 128, 40, 100), ResFieldLinear(146, 64, 7, 100),
+              ResFieldLinear(128, 3)]
+    layers = [l.to(dev) for l in layers]
+    frame = torch.tensor(37, device=dev)
+    probes = [torch.randn_like(l.weight) for l in layers]
+
+    def grads(fn):
+        for l in layers:
+            for p in l.parameters():
+                p.grad = None
+        ws = fn()
+        sum((w * p).sum() for w, p in zip(ws, probes)).backward()
+        out = [w.detach().clone() for w in ws]
+        g = {f"{i}.{k}": p.grad.clone() for i, l in enumerate(layers) for k, p in l.named_parameters() if p.grad is not None}
+        return out, g
+
+    w_ref, g_ref = grads(lambda: [l.effective(frame) for l in layers])
+    w1, g1 = grads(lambda: compose_resfield_weights(layers, frame))
+    w2, g2 = grads(lambda: compose_resfield_weights(layers, 37))          # a Python int works too
+    assert compose_resfield_weights(layers, frame)[0] is layers[0].weight   # layers without a residual pass through untouched
+    for a, b, c in zip(w_ref, w1, w2):
+        assert torch.equal(b, c) and (a - b).abs().max().item() <= 1e-6 * max(1.0, a.abs().max().item())
+    assert set(g1) == set(g_ref)
+    for k in g_ref:
+        assert torch.equal(g1[k], g2[k]), k
+        err = (g1[k] - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), 1e-12)
+        assert err <= 2e-5, (k, err)
+    assert (g1["1.weights_t"][torch.arange(100, device=dev) != 37] == 0).all()    # only the frame's row receives a gradient

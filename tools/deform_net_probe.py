@@ -264,6 +264,60 @@ def main():
                                                 for k in ref_out)
         res["net_forward_ms"] = timed(lambda: net(xyz, 0.37), a.steps, 5)
         res["net_forward_fused_mlps_ms"] = timed(lambda: net(xyz, 0.37, fused=True), a.steps, 5)
+    # the PRODUCT network (splatfields_amd.deform_field.SplatFields: tri-plane lookup, ResField composition and the six MLPs on HIP
+    # kernels) with the same stand-in plane decoder as generator, and decoder-free (the sampler owns 16 x 320 x 320 planes)
+    from splatfields_amd.deform_field import SplatFields
+    from splatfields_amd.triplane import TriPlaneSampler
+
+    class PlaneStack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.subs = nn.ModuleList([PlaneDecoder() for _ in range(3)])
+
+        def get_planes(self, frame_id=None):
+            return torch.cat([p() for p in self.subs], dim=0)
+
+    t_emb = torch.full((n, 1), 0.37, device=dev)
+    for key, enc in (("product", TriPlaneSampler(out_ch=16, plane_source=PlaneStack())), ("product_decoderfree", None)):
+        pnet = SplatFields(n_frames=50, composition_rank=10, encoder=enc, flow_model="offset").to(dev)   # run_owlii.sh:7 --flow_model offset
+
+        def p_net_step():
+            pnet.zero_grad(set_to_none=True)
+            xyz.grad = None
+            out = pnet(xyz, t_emb)
+            sum((v * v).mean() for k, v in out.items() if torch.is_tensor(v) and k != "flow").backward()
+
+        def p_full_step():
+            pnet.zero_grad(set_to_none=True)
+            xyz.grad = None
+            raster_step(pnet(xyz, t_emb))
+
+        res[key + "_net_fwd_bwd_ms"] = timed(p_net_step, a.steps, 5)
+        res[key + "_full_step_ms"] = timed(p_full_step, a.steps, 5)
+        with torch.no_grad():
+            res[key + "_net_forward_ms"] = timed(lambda: pnet(xyz, t_emb), a.steps, 5)
+        res[key + "_net_parameters"] = sum(p.numel() for p in pnet.parameters())
+        # the network's forward and backward as two HIP graphs (torch.cuda.make_graphed_callables: static shapes between two
+        # densification steps, no host synchronisation inside): the ~850 launches of a step are replayed without host work
+        try:
+            keys = ["means3D", "scales", "rotations", "opacity", "rgb"]
+            graphed = torch.cuda.make_graphed_callables(lambda x, tt: tuple(pnet(x, tt)[k] for k in keys), (xyz, t_emb))
+
+            def g_full_step():
+                pnet.zero_grad(set_to_none=True)
+                xyz.grad = None
+                raster_step(dict(zip(keys, graphed(xyz, t_emb))))
+
+            def g_net_step():
+                pnet.zero_grad(set_to_none=True)
+                xyz.grad = None
+                sum((v * v).mean() for v in graphed(xyz, t_emb)).backward()
+
+            res[key + "_graphed_net_fwd_bwd_ms"] = timed(g_net_step, a.steps, 5)
+            res[key + "_graphed_full_step_ms"] = timed(g_full_step, a.steps, 5)
+        except Exception as e:  # noqa: BLE001
+            res[key + "_graphed_error"] = repr(e)[:300]
+        del pnet
     res["net_share_of_step"] = res["net_fwd_bwd_ms"] / (res["net_fwd_bwd_ms"] + res["rasterizer_fwd_bwd_ms"])
     macs = sum(l.lin.weight.numel() for m in net.modules() if isinstance(m, GeneralMLP) for l in list(m.layers) + [m.out])
     res["mlp_macs_per_splat"] = macs + 2 * 48 * 48
