@@ -32,15 +32,21 @@ namespace {
 constexpr int kBucket = 16;                 // list entries per bucket = N of the MFMA
 constexpr int kBlkEntries = 32;             // granularity of a chunk of the tile list ("block" = half a wavefront's entries)
 constexpr int kBlocks = 8;                  // a chunk = up to 8 blocks = one list entry per thread
-// (quad, entry) slots per chunk; one block can need 32 x 16 = 512.  A slot holds 10 floats (12 when the caller supplies a
-// depth gradient, so that the record's depth rides along): 880 slots x 40 B + 10 KB of tables = 45 KB of LDS, three
-// workgroups per CU.  (768 slots = 40 KB = four per CU with the registers capped at 128 was measured and is slower,
-// 0.290 vs 0.277 ms: the kernel is issue-bound, a fourth workgroup adds spills and chunks, not throughput.)
+// (quad, entry) slots per pass over a chunk.  A slot holds 10 floats (12 when the caller supplies a depth gradient, so that
+// the record's depth rides along).  LDS per workgroup: slots + 10 KB of tables, three workgroups per CU (53 KB each).
+// (Four per CU with the registers capped at 128 was measured and is slower, 0.290 vs 0.277 ms: the kernel is issue-bound, a
+// fourth workgroup adds spills, not throughput.)
 #ifndef SR_BWD_CAP
-#define SR_BWD_CAP 880
+#define SR_BWD_CAP 1072
 #endif
-constexpr int kCap = SR_BWD_CAP;
-static_assert(kCap >= kBlkEntries * 16 && kCap % 16 == 0, "one block must always fit");
+#ifndef SR_BWD_CAP_DEPTH
+#define SR_BWD_CAP_DEPTH 880
+#endif
+// slots a pass may assign (40-byte / 48-byte slots: 53.5 / 53 KB of LDS per workgroup with the tables); a quad's run can
+// need 256, and reads run up to 15 slots past a run
+template <bool HAS_D> struct SlotCap { static constexpr int kCap = HAS_D ? SR_BWD_CAP_DEPTH : SR_BWD_CAP; };
+constexpr int kCapSlack = 16;
+static_assert(SR_BWD_CAP >= 256 && SR_BWD_CAP_DEPTH >= 256, "one quad's entries of a chunk must always fit");
 #ifndef SR_BWD_WAVES_PER_SIMD
 #define SR_BWD_WAVES_PER_SIMD 3   // register budget: 512 / 3 = 168 per lane
 #endif
@@ -144,22 +150,27 @@ __device__ __forceinline__ uint32_t row_scan_add_u32(uint32_t x) {
 // One list entry as the build phase holds it (one per thread and chunk).
 struct BwdEntry {
     int pos;            // list position (descending with the thread index), < 0: none
-    float4 r0, r1, r2;  // record quarters: (cx, cy, tau2, depth) (p, s, q, -log2 o) (r, g, b, depth)
-    uint32_t rect_xy, rect_w, first;   // tile rect origin / width of the splat, its first gradient slot
+    float2 c;           // splat centre in pixels
+    float4 r1, r2;      // record quarters (p, s, q, -log2 o) (r, g, b, depth)
+    uint32_t qm;        // quad-reach mask the forward computed for this (tile, entry)
+    uint32_t inst;      // instance index of the (splat, tile) pair: slot of the gradient scratch
 };
 
-__device__ __forceinline__ BwdEntry load_entry(const Geom& g, int pos, uint32_t id) {
+// Positions are clamped to 0 so that every load is unconditional (a thread without an entry loads entry 0 and drops it
+// through pos < 0): no branch, no merge with zeros behind the loads.
+__device__ __forceinline__ BwdEntry load_entry(const Geom& g, const uint32_t* ids, const uint32_t* qms, int pos, uint32_t tx, uint32_t ty) {
     BwdEntry e;
+    const int pc = pos > 0 ? pos : 0;
+    const uint32_t id = ids[pc];
+    const float4* rec = g.rec + 4 * (size_t)id;
     e.pos = pos;
-    e.r0 = e.r1 = e.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    e.rect_xy = e.rect_w = e.first = 0u;
-    if (pos >= 0) {
-        const float4* rec = g.rec + 4 * (size_t)id;
-        e.r0 = rec[0]; e.r1 = rec[1]; e.r2 = rec[2];
-        const float4 r3 = rec[3];
-        e.rect_xy = __float_as_uint(r3.x); e.rect_w = __float_as_uint(r3.y);
-        e.first = g.offsets[id];
-    }
+    e.c = *reinterpret_cast<const float2*>(rec);
+    e.r1 = rec[1]; e.r2 = rec[2];
+    const float4 r3 = rec[3];   // (tile rect origin, rect width): the instance index = the splat's first instance + the tile's
+                                // row-major position in its rect
+    const uint32_t rect_xy = __float_as_uint(r3.x), rect_w = __float_as_uint(r3.y);
+    e.inst = g.offsets[id] + (ty - (rect_xy >> 16)) * rect_w + (tx - (rect_xy & 0xffffu));
+    e.qm = qms[pc];
     return e;
 }
 
@@ -176,12 +187,12 @@ template <bool HAS_D>
 __device__ __forceinline__ void slot_put_record(float* sl, const BwdEntry& e) {
     if constexpr (HAS_D) {
         float4* d = reinterpret_cast<float4*>(sl);
-        d[0] = make_float4(e.r0.x, e.r0.y, __int_as_float(e.pos), e.r1.x);
+        d[0] = make_float4(e.c.x, e.c.y, __int_as_float(e.pos), e.r1.x);
         d[1] = make_float4(e.r1.y, e.r1.z, e.r1.w, e.r2.x);
         d[2] = make_float4(e.r2.y, e.r2.z, e.r2.w, 0.f);
     } else {
         float2* d = reinterpret_cast<float2*>(sl);
-        d[0] = make_float2(e.r0.x, e.r0.y);
+        d[0] = make_float2(e.c.x, e.c.y);
         d[1] = make_float2(__int_as_float(e.pos), e.r1.x);
         d[2] = make_float2(e.r1.y, e.r1.z);
         d[3] = make_float2(e.r1.w, e.r2.x);
@@ -289,7 +300,8 @@ __global__ void __launch_bounds__(kBlock, HAS_D ? 3 : SR_BWD_WAVES_PER_SIMD)   /
 k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im, const float* __restrict__ dL_dcolor,
                        const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha, float* __restrict__ slots) {
     constexpr int kF = SlotFmt<HAS_D>::kF;
-    __shared__ __attribute__((aligned(16))) float s_slot[kCap * kF];
+    constexpr int kCap = SlotCap<HAS_D>::kCap;
+    __shared__ __attribute__((aligned(16))) float s_slot[(kCap + kCapSlack) * kF];
     __shared__ float4 s_pixA[256];                   // per pixel of the tile: dL/d(r, g, b, depth)
     __shared__ float4 s_pixB[256];                   // (dL/dalpha, last contributor + 1 [int bits], T state, "behind . g" state)
     // the small tables are double-buffered by chunk parity: a wavefront may start testing the next chunk while others
@@ -310,7 +322,6 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
 
     const int tid = (int)threadIdx.x;
     const uint32_t* ids = b.sorted_id + start;
-    const uint16_t* qms = b.qmask + start;
 
     // How far the forward got, per 4x4 quad (Geom::tile_qlast, written at the end of the forward blend): list entries at
     // positions >= qlast[q] are behind the stop of every pixel of quad q.  The tile is uniform, so these are scalar loads;
@@ -327,15 +338,18 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
     const int bmax = __builtin_amdgcn_readfirstlane((int)bmax_u);   // uniform by construction; tell the compiler
     qlast_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)qlast_min);
 
-    // first chunk's entries: requested before anything else
+    // The list is replayed back to front in chunks of kChunk = one entry per thread; a chunk is always the next kChunk entries
+    // (when its (quad, entry) pairs exceed the slot buffer, the quads are served in several passes instead of shortening it).
+    // A chunk's entries are loaded at the end of the previous chunk, synchronously: measured on MI355X, every form of
+    // prefetch tried here -- a second register set swapped by unrolling the loop twice, LDS-direct loads into a staging area
+    // (0.337 ms: seven small copies per entry saturate the CU's copy path) -- was no faster than this (0.273 ms); with three
+    // workgroups per CU the other workgroups' replay already covers a chunk's gather.
+    constexpr int kChunk = kBlocks * kBlkEntries;
+    static_assert(kChunk == kBlock, "one list entry per thread");
+    if (bmax == 0) return;   // uniform: empty list, or no pixel of the tile blended anything
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
-    BwdEntry cur;
-    uint32_t cur_qm;
-    {
-        const int pos = hi - 1 - tid;
-        cur_qm = pos >= 0 ? (uint32_t)qms[pos] : 0u;
-        cur = load_entry(g, pos, pos >= 0 ? ids[pos] : 0u);
-    }
+    const uint32_t* qms = b.qmask + start;
+    BwdEntry cur = load_entry(g, ids, qms, hi - 1 - tid, (uint32_t)tx, (uint32_t)ty);
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -370,12 +384,12 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
 
     int par = 0;   // chunk parity: which copy of the small tables
     SR_PHASE(0);   // preamble
+
     while (hi > 0) {
         // ---------------- (A) which quads does this thread's entry reach?  (mask from the forward, minus finished quads) ----
-        uint32_t qm = 0u, inst = 0u;
+        uint32_t qm = 0u;
         if (cur.pos >= 0) {
-            inst = cur.first + ((uint32_t)ty - (cur.rect_xy >> 16)) * cur.rect_w + ((uint32_t)tx - (cur.rect_xy & 0xffffu));
-            qm = cur_qm;
+            qm = cur.qm & 0xffffu;
             if ((uint32_t)cur.pos >= qlast_min) {   // behind the last contributor of every pixel of some quad
 #pragma unroll
                 for (int q = 0; q < 16; ++q) if ((uint32_t)cur.pos >= qlast[q]) qm &= ~(1u << q);
@@ -393,178 +407,195 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             if (lane < 16) { s_mask[par][lane][2 * wave] = mlo; s_mask[par][lane][2 * wave + 1] = mhi; }
         }
         SR_PHASE(1);   // (A) test + ballots
-        __syncthreads();
+        lds_barrier();
         SR_PHASE(2);   // barrier after (A)
-        // ---------------- (B) slot assignment: longest prefix of blocks that fits (every wavefront computes the same) --------
-        int used;
+        // ---------------- (B) slot assignment (every wavefront computes the same) --------
+        // Quad q's entries of the chunk occupy a run of slots (no padding between runs: a bucket that reads past the end of its
+        // run sees the next run's slots, or the slack behind the buffer, and masks them).  Usually all sixteen runs fit the
+        // slot buffer at once; when they do not (dense footprints), the quads are served in several PASSES of consecutive
+        // quads, each pass packing its runs from slot 0.  The chunk itself is always the next kChunk entries, which is what
+        // lets the next chunk be fetched before this one has been looked at.
+        uint32_t pass_starts = 1u;   // uniform: bit q set = a pass starts at quad q
         {
             const int q = nl;   // the four rows of a wavefront compute the same thing, too
-            uint32_t len = 0u, used_v = 0u;
+            uint32_t len = 0u;
             uint32_t first_of[kBlocks];
-            bool open = true;
 #pragma unroll
             for (int blk = 0; blk < kBlocks; ++blk) {
                 first_of[blk] = len;
-                const uint32_t c = (uint32_t)__popc(s_mask[par][q][blk]);
-                const uint32_t padded = (len + c + 15u) & ~15u;
-                const bool fits = row_allsum_u32(padded) <= (uint32_t)kCap;
-                if (open && fits) { len += c; used_v = blk + 1; } else open = false;
+                len += (uint32_t)__popc(s_mask[par][q][blk]);
             }
-            const uint32_t padded = (len + 15u) & ~15u;
-            const uint32_t base = row_scan_add_u32(padded) - padded;
-            if (lane < 16) {   // all four wavefronts write the same values; each reads back only its own writes
-                s_qlen[par][q] = len; s_qbase[par][q] = base;
+            uint32_t run = 0u, my_base = 0u;
 #pragma unroll
-                for (int blk = 0; blk < kBlocks; ++blk) s_bb[par][q][blk] = (uint16_t)(base + first_of[blk]);
+            for (int qq = 0; qq < 16; ++qq) {   // greedy partition into passes; values are wave-uniform (readlane)
+                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)len, qq);
+                if (run + pq > (uint32_t)kCap) { pass_starts |= 1u << qq; run = 0u; }
+                my_base = q == qq ? run : my_base;
+                run += pq;
             }
-            used = __builtin_amdgcn_readfirstlane((int)used_v);
+            if (lane < 16) {   // all four wavefronts write the same values; each reads back only its own writes
+                s_qlen[par][q] = len; s_qbase[par][q] = my_base;
+#pragma unroll
+                for (int blk = 0; blk < kBlocks; ++blk) s_bb[par][q][blk] = (uint16_t)(my_base + first_of[blk]);
+            }
             if (threadIdx.x == 0) s_ticket[par ^ 1] = 0u;   // every wavefront has left the previous chunk's replay
 #ifdef SR_BWD_STATS
             { const uint32_t pairs = row_allsum_u32(len);
-              if (threadIdx.x == 0) { SR_STAT_ADD(0, min(hi, kBlkEntries * used)); SR_STAT_ADD(1, pairs); SR_STAT_ADD(5, 1); } }
+              if (threadIdx.x == 0) { SR_STAT_ADD(0, min(hi, kChunk)); SR_STAT_ADD(1, pairs); SR_STAT_ADD(5, 1); } }
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        // next chunk's entry of this thread: the splat index is requested now, its record after the scatter -- both
-        // latencies hide behind the replay
-        const int npos = hi - kBlkEntries * used - 1 - tid;
-        const uint32_t nid = npos >= 0 ? ids[npos] : 0u;
-        const uint32_t nqm = npos >= 0 ? (uint32_t)qms[npos] : 0u;
-        // ---------------- (C) scatter the records into the quads' slot runs ----------------
-        if (myblk < used) {
-            uint32_t m = qm;
-            while (m) {
-                const int q = __builtin_ctz(m);
-                m &= m - 1u;
-                const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
-                slot_put_record<HAS_D>(s_slot + kF * slot, cur);
-            }
-        }
-        const BwdEntry nxt = load_entry(g, npos, nid);
-        SR_PHASE(3);   // (B) + (C)
-        __syncthreads();
-        SR_PHASE(4);   // barrier after (C)
-        // ---------------- (D) replay: each wavefront walks the buckets of its four quads ----------------
-        // Quads are handed out through an LDS ticket (which wavefront replays which quad does not reach the results: every
-        // quad's sums go to its own slots and are combined in a fixed order).  The next ticket is drawn one quad ahead.
-        uint32_t ticket = 0u;
-        if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
+        float4 s0 = zero4, s1 = zero4;
+        float2 s2 = make_float2(0.f, 0.f);
+        pass_starts = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass_starts) | 0x10000u;   // sentinel: "pass" 17 starts at 16
 #pragma unroll 1
-        for (;;) {
-            const int q = __builtin_amdgcn_readfirstlane((int)ticket);
-            if (q >= 16) break;
-            if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
-            const int qy = q >> 2, qx = q & 3;
-            const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[par][q]);
-            if (len == 0) continue;
-            const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[par][q]);
-            const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
-            QuadCtx c;
-            float ST[4], SB[4];
-            c.pyf = ty0f + (float)(4 * qy + k);
-            const float Y = (float)(4 * qy + k) - 7.5f;
-            // MFMA A operands: this lane supplies row m = lane & 15 of the 16 x 4 operand for pixel row k.
-            // rows 0-5: pixel monomials 1, X, Y, X^2, XY, Y^2 = c0 + X (c1 + X c2); rows 6-9: dL/d(r, g, b, depth)
-            const float c0 = nl == 0 ? 1.0f : nl == 2 ? Y : nl == 5 ? Y * Y : 0.0f;
-            const float c1 = nl == 1 ? 1.0f : nl == 4 ? Y : 0.0f;
-            const float c2 = nl == 3 ? 1.0f : 0.0f;
-            const float w6 = nl == 6 ? 1.0f : 0.0f, w7 = nl == 7 ? 1.0f : 0.0f, w8 = nl == 8 ? 1.0f : 0.0f, w9 = nl == 9 ? 1.0f : 0.0f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
-                c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
-                c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
-                c.pxf[t] = tx0f + (float)(4 * qx + t);
-                const float X = (float)(4 * qx + t) - 7.5f;
-                c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
-                c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
-            }
-            // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
-            // interleave.  The slots of the next iteration are read while this one computes.
-            const int last_bucket = ((len - 1) >> 4) << 4;   // first entry of the quad's last bucket
-            auto slot_of = [&](int i, bool up) { return s_slot + kF * (base + min(i, last_bucket) + (up ? nl : 15 - nl)); };
-            int i0 = 0;
-            float* sa = slot_of(0, true);
-            float* sb = slot_of(kBucket, false);
-            SlotIn ea = slot_get_record<HAS_D>(sa), eb = slot_get_record<HAS_D>(sb);
-#pragma unroll 1
-            for (; i0 + kBucket < len; i0 += 2 * kBucket) {
-                float* sa_n = slot_of(i0 + 2 * kBucket, true);
-                float* sb_n = slot_of(i0 + 3 * kBucket, false);
-                const SlotIn na = slot_get_record<HAS_D>(sa_n), nb = slot_get_record<HAS_D>(sb_n);
-                const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
-                slot_mask_invalid(eb, vb);
-                f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
-#ifdef SR_BWD_STATS
-                if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
-#endif
-                replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
-                replay_bucket<false, HAS_D>(c, eb, ST, SB, D1b, D2b, lane);
-                // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
-                if (k < 3) {
-                    slot_put_sums<HAS_D>(sa, k, D1a + D2a);
-                    if (vb) slot_put_sums<HAS_D>(sb, k, D1b + D2b);
+        for (int q_lo = 0; q_lo < 16;) {
+            const int q_hi = __builtin_ctz(pass_starts & ~((2u << q_lo) - 1u));   // next pass start behind q_lo
+            const uint32_t pmask = ((1u << q_hi) - 1u) & ~((1u << q_lo) - 1u);
+            // ---------------- (C) scatter the records into the quads' slot runs ----------------
+            {
+                uint32_t m = qm & pmask;
+                while (m) {
+                    const int q = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
+                    slot_put_record<HAS_D>(s_slot + kF * slot, cur);
                 }
-                sa = sa_n; sb = sb_n;
-                ea = na; eb = nb;
             }
-            const bool tail = i0 < len;   // a last single bucket (UP): its carries end in lane 15, otherwise they are in lane 0
-            if (tail) {
-                const bool va = i0 + nl < len;
-                slot_mask_invalid(ea, va);
-                f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a;
-#ifdef SR_BWD_STATS
-                if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
-#endif
-                replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
-                if (k < 3 && va) slot_put_sums<HAS_D>(sa, k, D1a + D2a);
-            }
-            if (nl == (tail ? 15 : 0)) {
+            if (threadIdx.x == 0) s_ticket[par] = (uint32_t)q_lo;   // nobody draws tickets between the barrier behind the last
+                                                                     // replay and the one below
+            SR_PHASE(3);   // (B) + (C)
+            lds_barrier();
+            SR_PHASE(4);   // barrier after (C)
+            // ---------------- (D) replay: each wavefront walks the buckets of its quads ----------------
+            // Quads are handed out through an LDS ticket (which wavefront replays which quad does not reach the results: every
+            // quad's sums go to its own slots and are combined in a fixed order).  The next ticket is drawn one quad ahead.
+            uint32_t ticket = 0u;
+            if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
+#pragma unroll 1
+            for (;;) {
+                const int q = __builtin_amdgcn_readfirstlane((int)ticket);
+                if (q >= q_hi) break;
+                if (lane == 0) ticket = atomicAdd(&s_ticket[par], 1u);
+                const int qy = q >> 2, qx = q & 3;
+                const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[par][q]);
+                if (len == 0) continue;
+                const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[par][q]);
+                const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
+                QuadCtx c;
+                float ST[4], SB[4];
+                c.pyf = ty0f + (float)(4 * qy + k);
+                const float Y = (float)(4 * qy + k) - 7.5f;
+                // MFMA A operands: this lane supplies row m = lane & 15 of the 16 x 4 operand for pixel row k.
+                // rows 0-5: pixel monomials 1, X, Y, X^2, XY, Y^2 = c0 + X (c1 + X c2); rows 6-9: dL/d(r, g, b, depth)
+                const float c0 = nl == 0 ? 1.0f : nl == 2 ? Y : nl == 5 ? Y * Y : 0.0f;
+                const float c1 = nl == 1 ? 1.0f : nl == 4 ? Y : 0.0f;
+                const float c2 = nl == 3 ? 1.0f : 0.0f;
+                const float w6 = nl == 6 ? 1.0f : 0.0f, w7 = nl == 7 ? 1.0f : 0.0f, w8 = nl == 8 ? 1.0f : 0.0f, w9 = nl == 9 ? 1.0f : 0.0f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    float* st = reinterpret_cast<float*>(&s_pixB[prow + t]);
-                    st[2] = ST[t]; st[3] = SB[t];
+                    const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
+                    c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
+                    c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
+                    c.pxf[t] = tx0f + (float)(4 * qx + t);
+                    const float X = (float)(4 * qx + t) - 7.5f;
+                    c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
+                    c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
+                }
+                // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
+                // interleave.  The slots of the next iteration are read while this one computes.
+                const int last_bucket = ((len - 1) >> 4) << 4;   // first entry of the quad's last bucket
+                auto slot_of = [&](int i, bool up) { return s_slot + kF * (base + min(i, last_bucket) + (up ? nl : 15 - nl)); };
+                int i0 = 0;
+                float* sa = slot_of(0, true);
+                float* sb = slot_of(kBucket, false);
+                SlotIn ea = slot_get_record<HAS_D>(sa), eb = slot_get_record<HAS_D>(sb);
+#pragma unroll 1
+                for (; i0 + kBucket < len; i0 += 2 * kBucket) {
+                    float* sa_n = slot_of(i0 + 2 * kBucket, true);
+                    float* sb_n = slot_of(i0 + 3 * kBucket, false);
+                    const SlotIn na = slot_get_record<HAS_D>(sa_n), nb = slot_get_record<HAS_D>(sb_n);
+                    const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
+                    slot_mask_invalid(eb, vb);
+                    f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
+#ifdef SR_BWD_STATS
+                    if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
+#endif
+                    replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
+                    replay_bucket<false, HAS_D>(c, eb, ST, SB, D1b, D2b, lane);
+                    // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
+                    if (k < 3) {
+                        slot_put_sums<HAS_D>(sa, k, D1a + D2a);
+                        if (vb) slot_put_sums<HAS_D>(sb, k, D1b + D2b);
+                    }
+                    sa = sa_n; sb = sb_n;
+                    ea = na; eb = nb;
+                }
+                const bool tail = i0 < len;   // a last single bucket (UP): its carries end in lane 15, otherwise they are in lane 0
+                if (tail) {
+                    const bool va = i0 + nl < len;
+                    slot_mask_invalid(ea, va);
+                    f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a;
+#ifdef SR_BWD_STATS
+                    if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
+#endif
+                    replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
+                    if (k < 3 && va) slot_put_sums<HAS_D>(sa, k, D1a + D2a);
+                }
+                if (nl == (tail ? 15 : 0)) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float* st = reinterpret_cast<float*>(&s_pixB[prow + t]);
+                        st[2] = ST[t]; st[3] = SB[t];
+                    }
                 }
             }
-        }
-        SR_PHASE(5);   // (D) replay
-        __syncthreads();
-        SR_PHASE(6);   // barrier after (D)
-        // ---------------- (E) combine the quads' sums of every entry, shift the moments to the splat centre ----------------
-        if (myblk < used && cur.pos >= 0) {
-            float4 s0 = zero4, s1 = zero4;
-            float2 s2 = make_float2(0.f, 0.f);
-            uint32_t m = qm;
-            while (m) {   // ascending quad index: fixed summation order
-                const int q = __builtin_ctz(m);
-                m &= m - 1u;
-                const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
-                float4 a, cc; float2 d;
-                slot_get_sums<HAS_D>(s_slot + kF * slot, a, cc, d);
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-                s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
-                s2.x += d.x; if (HAS_D) s2.y += d.y;
+            SR_PHASE(5);   // (D) replay
+            lds_barrier();
+            SR_PHASE(6);   // barrier after (D)
+            // ---------------- (E) add up the quads' sums of every entry (ascending quad index: fixed summation order) ----------
+            if (cur.pos >= 0) {
+                uint32_t m = qm & pmask;
+                while (m) {
+                    const int q = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
+                    float4 a, cc; float2 d;
+                    slot_get_sums<HAS_D>(s_slot + kF * slot, a, cc, d);
+                    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                    s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
+                    s2.x += d.x; if (HAS_D) s2.y += d.y;
+                }
             }
+            if (q_hi < 16) lds_barrier();   // the next pass overwrites the slots
+            q_lo = q_hi;
+        }
+        // no barrier here: the next chunk's (A) touches only the other copy of the small tables, and its scatter (C) comes
+        // after the barrier that follows (A)
+        hi -= kChunk;
+        par ^= 1;
+        // `cur` is dead except for the few values the final store needs: the next chunk's entries are requested before this
+        // chunk's stores go out
+        const float2 centre = cur.c;
+        const size_t inst = cur.inst;
+        const bool has_entry = cur.pos >= 0;
+        if (hi > 0) cur = load_entry(g, ids, qms, hi - 1 - tid, (uint32_t)tx, (uint32_t)ty);   // uniform condition
+        // shift the moments to the splat centre and store the instance's gradient slot
+        if (has_entry) {
             // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
-            const float ox = cur.r0.x - (tx0f + 7.5f), oy = cur.r0.y - (ty0f + 7.5f);
+            const float ox = centre.x - (tx0f + 7.5f), oy = centre.y - (ty0f + 7.5f);
             const float M0 = s0.x, MX = s0.y, MY = s0.z, MXX = s0.w, MXY = s1.x, MYY = s1.y;
             const float Sx = ox * M0 - MX, Sy = oy * M0 - MY;
             const float Sxx = fmaf(ox, Sx - MX, MXX);               // ox^2 M0 - 2 ox MX + MXX
             const float Syy = fmaf(oy, Sy - MY, MYY);
             const float Sxy = fmaf(ox, Sy, MXY) - oy * MX;          // ox oy M0 - ox MY - oy MX + MXY
-            slot4[(size_t)inst * 3] = make_float4(M0, Sx, Sy, Sxx);
-            slot4[(size_t)inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
-            slot4[(size_t)inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
+            slot4[inst * 3] = make_float4(M0, Sx, Sy, Sxx);
+            slot4[inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
+            slot4[inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
             b.reached[inst] = 1;
         }
-        // no barrier here: the next chunk's (A) touches only the other copy of the small tables, and its scatter (C) comes
-        // after the barrier that follows (A)
-        hi -= kBlkEntries * used;
-        cur = nxt;
-        cur_qm = nqm;
-        par ^= 1;
         SR_PHASE(7);   // (E) combine
     }
 #ifdef SR_BWD_STATS

@@ -90,10 +90,13 @@ struct Binning {
                          //     -- ONE 8-byte store per instance from the scatter; the payload is the key's low half
     uint64_t* keys;      // [R] ping-pong buffer A of the long-list merge path
     uint64_t* keys_tmp;  // [R] ping-pong buffer B
-    uint32_t* sorted_id; // [R] splat index, per tile front-to-back.  The instance index (slot of the backward scratch) is
-                         //     not stored: offsets[splat] + row-major position of the tile inside the splat's tile rect
-    uint16_t* qmask;     // [R] per list entry (same order as sorted_id): which 4x4-pixel quads of its tile the splat can reach
-                         //     with alpha >= 1/255 (bit 4 qy + qx, quadmask.h).  Computed once by the forward blend while it stages
+    uint32_t* sorted_id; // [R] splat index, per tile front-to-back.  The instance index a (splat, tile) pair owns in the backward scratch
+                         //     is not stored: offsets[splat] + row-major position of the tile inside the splat's tile rect (record
+                         //     quarter 3).  (Precomputing it per list entry in the per-tile sort was measured: +45 us there for the
+                         //     two gathers per entry at the tail of a VALU-bound kernel, nothing gained in the backward.)
+    uint32_t* qmask;     // [R] per list entry (same order as sorted_id): which 4x4-pixel quads of its tile the splat can reach
+                         //     with alpha >= 1/255 (bit 4 qy + qx, quadmask.h; 32-bit words: the backward fetches them with
+                         //     LDS-direct loads, whose granule is a dword).  Computed once by the forward blend while it stages
                          //     the entry, used there for the sub-tile culling and by the backward blend for its bucketing
     uint8_t* reached;    // [R] per tile-splat INSTANCE (index = offsets[splat] + position of the tile in the splat's rect): 1 once
                          //     the backward blend has written its gradient slot.  Cleared by the scatter (k_emit walks the
@@ -157,7 +160,7 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     t.keys = c.take<uint64_t>(r);
     t.keys_tmp = c.take<uint64_t>(r);
     t.sorted_id = c.take<uint32_t>(r);
-    t.qmask = c.take<uint16_t>(r);
+    t.qmask = c.take<uint32_t>(r);
     t.reached = c.take<uint8_t>(r);
     t.capacity = (uint32_t)(R > 0 ? R : 0);
     if (b) *b = t;
@@ -211,6 +214,28 @@ __device__ __forceinline__ void store_stream(float4* p, const float4 v) {
     const v4f_nt x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<v4f_nt*>(p));
 }
+
+// Asynchronous 16-byte-per-lane copy memory -> LDS (global_load_lds_dwordx4): lane l's 16 bytes at `src` land at LDS byte
+// address `lds_base` + 16 l, with no register staging and no ds_write.  Written as inline assembly on purpose: hipcc drains
+// every outstanding memory operation at the next barrier / first use when it tracks such a copy itself, whereas these
+// requests are meant to stay in flight across a whole batch of blending; the kernel waits for them with lds_copy_wait().
+// M0 (the LDS base) is reserved by the compiler: saved and restored inside the statement.
+__device__ __forceinline__ void lds_copy16_async(const void* src, uint32_t lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+// the 4-byte form: lane l's dword lands at `lds_base` + 4 l
+__device__ __forceinline__ void lds_copy4_async(const void* src, uint32_t lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void lds_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only (this wavefront's LDS operations are complete before it arrives): unlike
+// __syncthreads() it carries no release fence, so requests to global memory stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of the flat address
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_add(float v) {

@@ -75,22 +75,6 @@ __device__ __forceinline__ void publish_tile_reach(const Geom& g, int tile, uint
 // ------------------------------------------------------------------------------------------
 // Forward
 // ------------------------------------------------------------------------------------------
-// Asynchronous 16-byte-per-lane copy memory -> LDS (global_load_lds_dwordx4): lane l's 16 bytes at `src` land at LDS byte
-// address `lds_base` + 16 l, with no register staging and no ds_write.  Written as inline assembly on purpose: hipcc drains
-// every outstanding memory operation at the next barrier / first use when it tracks such a copy itself, whereas these
-// requests are meant to stay in flight across a whole batch of blending; the kernel waits for them with lds_copy_wait().
-// M0 (the LDS base) is reserved by the compiler: saved and restored inside the statement.
-__device__ __forceinline__ void lds_copy16_async(const void* src, uint32_t lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void lds_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// Workgroup barrier that orders LDS traffic only (this wavefront's LDS operations are complete before it arrives): unlike
-// __syncthreads() it carries no release fence, so requests to global memory stay in flight across it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)p; }   // low half of the flat address
-
 __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const Geom g, const Binning b, const Image im,
                                                            float* __restrict__ out_color, float* __restrict__ out_depth,
                                                            float* __restrict__ out_alpha) {
@@ -164,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
         if (i < end) {
             const float4 r0 = s_r0[buf][slot], r1 = s_r1[buf][slot];
             qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
-            b.qmask[i] = (uint16_t)qm;
+            b.qmask[i] = qm;
         }
 #endif
         s_qm[buf][slot] = (uint16_t)qm;
@@ -338,18 +322,18 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         // instance index (slot of the gradient scratch) of this thread's list entry = the splat's first instance + row-major
         // position of this tile inside the splat's tile rect (which rides in the record's fourth quarter).  The offsets
         // gather is issued last and consumed only after the blend loop, so its latency is never waited for.
-        uint32_t inst_first = 0u, inst_local = 0u;
+        uint32_t inst_v = 0u;
         if ((int)threadIdx.x < cnt) {
             const uint32_t pos = start + (uint32_t)(top - 1 - (int)threadIdx.x);
             const uint32_t id = b.sorted_id[pos];
             const float4* rec = g.rec + 4 * (size_t)id;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            inst_first = g.offsets[id];
+            const uint32_t inst_first = g.offsets[id];
             s_r0[threadIdx.x] = r0;
             s_r1[threadIdx.x] = r1;
             s_r2[threadIdx.x] = r2;
             const uint32_t xy = __float_as_uint(r3.x), rw = __float_as_uint(r3.y);
-            inst_local = ((uint32_t)ty - (xy >> 16)) * rw + ((uint32_t)tx - (xy & 0xffffu));
+            inst_v = inst_first + ((uint32_t)ty - (xy >> 16)) * rw + ((uint32_t)tx - (xy & 0xffffu));
         }
         {
             float4* acc = &s_acc[0][0][0];
@@ -433,7 +417,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const int e = threadIdx.x;
-            const size_t inst = (size_t)inst_first + inst_local;
+            const size_t inst = (size_t)inst_v;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const float4 a0 = s_acc[0][e][q], a1 = s_acc[1][e][q], a2 = s_acc[2][e][q], a3 = s_acc[3][e][q];
