@@ -408,6 +408,20 @@ int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void*
     return check_hip(hipGetLastError(), "mlp_weight_grad");
 }
 
+int sr_mlp_input_forward(int n_points, int multires, int n_features, int row, const float* xyz, const float* features, float* x0,
+                         void* hip_stream) {
+    if (sr::launch_mlp_input_forward(n_points, multires, n_features, row, xyz, features, x0, static_cast<hipStream_t>(hip_stream)))
+        return fail("bad arguments to sr_mlp_input_forward (row a multiple of 4 and >= 3 + 6 multires + n_features, multires <= 16)");
+    return check_hip(hipGetLastError(), "mlp_input_forward");
+}
+
+int sr_mlp_input_backward(int n_points, int multires, int n_features, int row, const float* xyz, const float* dL_dx0, float* dL_dxyz,
+                          float* dL_dfeatures, void* hip_stream) {
+    if (sr::launch_mlp_input_backward(n_points, multires, n_features, row, xyz, dL_dx0, dL_dxyz, dL_dfeatures, static_cast<hipStream_t>(hip_stream)))
+        return fail("bad arguments to sr_mlp_input_backward");
+    return check_hip(hipGetLastError(), "mlp_input_backward");
+}
+
 int sr_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, void* hip_stream) {
     if (sr::launch_resfield_compose(n_jobs, jobs, frame, static_cast<hipStream_t>(hip_stream)))
         return fail("sr_resfield_compose: unsupported job list (<= SR_RESFIELD_MAX_JOBS jobs, count a multiple of 4, 16-byte aligned "

@@ -392,17 +392,25 @@ __device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start,
     }
 }
 
-// lists of 1..1024 entries: one register network, one workgroup (256 threads) per tile, LDS 8 KiB
+// forward declaration (defined below): runs of 1024 sorted by the register network + one multi-way merge pass in LDS
+template <int CAP, int THREADS, typename Emit>
+__device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, Emit&& emit);
+
+// Lists of 1..2048 entries, one workgroup (256 threads) per tile, LDS 16 KiB: up to 1024 entries one register network;
+// 1025..2048 two runs sorted one after the other + the merge pass.  One launch for what used to be two (a launch per length
+// class spins up one workgroup per tile just to find out that most lists belong to the other class: at the headline
+// workload 2500 workgroups each, plus the launch gap, for ~40 % of the tiles).
 __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Binning b) {
-    __shared__ uint64_t skey[1024];
+    __shared__ uint64_t skey[2048];
     if (g.total[0] > b.capacity) return;
     const uint32_t tile = g.tile_order[blockIdx.x];  // longest lists first
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
-    if (n == 0u || n > 1024u) return;
+    if (n == 0u || n > 2048u) return;
     if (n <= 256u) sort_tile_regs<256, 1>(b, start, n, skey);
     else if (n <= 512u) sort_tile_regs<512, 2>(b, start, n, skey);
-    else sort_tile_regs<1024, 4>(b, start, n, skey);
+    else if (n <= 1024u) sort_tile_regs<1024, 4>(b, start, n, skey);
+    else sort_block_lds<2048, 256>(b, start, n, skey, [&](uint32_t rank, uint64_t key) { b.sorted_id[start + rank] = (uint32_t)key; });
 }
 
 // Sorts n <= CAP entries starting at b.ent[first]: runs of 1024 are sorted by the register network into LDS (one
@@ -529,9 +537,7 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
     auto lds = [](int cap, int) { return (size_t)cap * 8; };
-    hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);
-    if (max_len >= 0 && max_len <= 1024) return;
-    hipLaunchKernelGGL((k_sort_tiles_merge<1024, 2048, 512>), dim3(tiles), dim3(512), lds(2048, 512), st, g, b, tiles);
+    hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);   // every list of up to 2048 entries
     if (max_len >= 0 && max_len <= 2048) return;
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), 2, (int)lds(4096, 1024));
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), 3, (int)lds(8192, 1024));

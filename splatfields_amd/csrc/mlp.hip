@@ -542,3 +542,80 @@ int launch_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long l
 }
 
 }  // namespace sr
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Network input of a GeneralMLP (reference utils/time_utils.py:9-57 `get_embedder` + :178-181): row p of the padded input
+// matrix = [ x (3) | sin(2^0 x) (3) | cos(2^0 x) (3) | ... | sin(2^(L-1) x) | cos(2^(L-1) x) | features (F) | 0 ... ].
+// One launch instead of the reference's 2 L multiplies, 2 L sin / cos, two concatenations and the padding copy (and as many
+// again backward): ~60 small kernels per network and step.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace sr {
+
+__global__ void __launch_bounds__(kBlock) k_mlp_input_forward(int N, int L, int F, int row, const float* __restrict__ xyz,
+                                                              const float* __restrict__ feat, float* __restrict__ x0) {
+    const int q = row >> 2;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)N * q) return;
+    const int p = (int)(t / q), c0 = 4 * (int)(t % q);
+    const float x[3] = {xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2]};
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i;
+        float o = 0.0f;
+        if (c < 3) o = x[c];
+        else if (c < 3 + 6 * L) {
+            const int k = c - 3, j = k / 6, r = k - 6 * j;
+            const float a = x[r < 3 ? r : r - 3] * (float)(1 << j);
+            o = r < 3 ? sinf(a) : cosf(a);
+        } else if (c < 3 + 6 * L + F) o = feat[(size_t)p * F + (c - 3 - 6 * L)];
+        v[i] = o;
+    }
+    reinterpret_cast<float4*>(x0)[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// d_xyz[p] = g[0:3] + sum_j 2^j (cos(2^j x) g_sin_j - sin(2^j x) g_cos_j);  d_feat[p] = g[3 + 6 L : 3 + 6 L + F]
+__global__ void __launch_bounds__(kBlock) k_mlp_input_backward(int N, int L, int F, int row, const float* __restrict__ xyz,
+                                                               const float* __restrict__ g, float* __restrict__ d_xyz, float* __restrict__ d_feat) {
+    const int per = 1 + (F + 3) / 4;   // thread 0 of a point: the position gradient; the others: 4 feature columns each
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)N * per) return;
+    const int p = (int)(t / per), part = (int)(t % per);
+    const float* gp = g + (size_t)p * row;
+    if (part == 0) {
+        if (!d_xyz) return;
+        float d[3] = {gp[0], gp[1], gp[2]};
+        const float x[3] = {xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2]};
+        for (int j = 0; j < L; ++j) {
+            const float f = (float)(1 << j);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float sn, cs;
+                sincosf(x[r] * f, &sn, &cs);
+                d[r] += f * (cs * gp[3 + 6 * j + r] - sn * gp[3 + 6 * j + 3 + r]);
+            }
+        }
+        d_xyz[3 * (size_t)p] = d[0]; d_xyz[3 * (size_t)p + 1] = d[1]; d_xyz[3 * (size_t)p + 2] = d[2];
+    } else if (d_feat) {
+        const int f0 = 4 * (part - 1);
+        for (int i = f0; i < min(f0 + 4, F); ++i) d_feat[(size_t)p * F + i] = gp[3 + 6 * L + i];
+    }
+}
+
+int launch_mlp_input_forward(int N, int L, int F, int row, const float* xyz, const float* feat, float* x0, hipStream_t st) {
+    if (N < 0 || L < 0 || L > 16 || F < 0 || (row & 3) || row < 3 + 6 * L + F || (F > 0 && !feat) || !xyz || !x0) return 1;
+    if (N == 0) return 0;
+    const long long threads = (long long)N * (row >> 2);
+    hipLaunchKernelGGL(k_mlp_input_forward, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, L, F, row, xyz, feat, x0);
+    return 0;
+}
+
+int launch_mlp_input_backward(int N, int L, int F, int row, const float* xyz, const float* g, float* d_xyz, float* d_feat, hipStream_t st) {
+    if (N < 0 || L < 0 || L > 16 || F < 0 || row < 3 + 6 * L + F || !xyz || !g) return 1;
+    if (N == 0) return 0;
+    const long long threads = (long long)N * (1 + (F + 3) / 4);
+    hipLaunchKernelGGL(k_mlp_input_backward, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, L, F, row, xyz, g, d_xyz, d_feat);
+    return 0;
+}
+
+}  // namespace sr

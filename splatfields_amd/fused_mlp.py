@@ -312,6 +312,81 @@ class _FusedMLPFn(torch.autograd.Function):
         return (dx0[:, :d_in] if need_input else None, None, None, None, *dWs, *dbs)
 
 
+class _FusedMLPPointsFn(torch.autograd.Function):
+    """The same network fed from the points themselves: the input matrix [x | sin / cos encodings | features | padding] is
+    built by one kernel (sr_mlp_input_forward) straight into the padded layout the chain kernel reads, and its backward
+    (sr_mlp_input_backward) turns dL/dx0 into dL/dxyz and dL/dfeatures -- instead of ~60 small PyTorch kernels per network
+    and step for the encoding, the concatenations, the padding and their backward."""
+
+    @staticmethod
+    def forward(ctx, xyz, feat, shape: _Shape, slope: float, multires: int, grad_enabled: bool, *params):
+        lib = _lib.load()
+        L = shape.n_layers
+        weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
+        biases = [p.detach().to(torch.float32).contiguous() for p in params[L:]]
+        dev, n = xyz.device, xyz.shape[0]
+        x32 = xyz.detach().to(torch.float32).contiguous()
+        f32 = feat.detach().to(torch.float32).contiguous() if feat is not None else None
+        n_feat = 0 if f32 is None else f32.shape[1]
+        x0 = torch.empty(n, shape.mem_pad, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sr_mlp_input_forward(n, multires, n_feat, shape.mem_pad, C.c_void_p(x32.data_ptr()),
+                                                C.c_void_p(f32.data_ptr()) if f32 is not None else None, C.c_void_p(x0.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        need = grad_enabled and any(ctx.needs_input_grad)
+        y, acts = _forward(shape, x0, weights, biases, slope, save=need)
+        if need:
+            ctx.shape, ctx.slope, ctx.multires, ctx.n_feat = shape, slope, multires, n_feat
+            ctx.save_for_backward(x32, x0, acts, y, *weights)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dY):
+        lib = _lib.load()
+        shape, slope = ctx.shape, ctx.slope
+        x32, x0, acts, y, *weights = ctx.saved_tensors
+        L, dev, n = shape.n_layers, x0.device, x0.shape[0]
+        need_xyz, need_feat = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.n_feat > 0
+        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_xyz or need_feat)
+        d_xyz = torch.empty(n, 3, dtype=torch.float32, device=dev) if need_xyz else None
+        d_feat = torch.empty(n, ctx.n_feat, dtype=torch.float32, device=dev) if need_feat else None
+        if need_xyz or need_feat:
+            with torch.cuda.device(dev):
+                _lib.check(lib.sr_mlp_input_backward(n, ctx.multires, ctx.n_feat, shape.mem_pad, C.c_void_p(x32.data_ptr()),
+                                                     C.c_void_p(dx0.data_ptr()), C.c_void_p(d_xyz.data_ptr()) if need_xyz else None,
+                                                     C.c_void_p(d_feat.data_ptr()) if need_feat else None,
+                                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        dWs, dbs = [None] * L, [None] * L
+        if any(ctx.needs_input_grad[6:]):
+            dWs, dbs = _weight_grads(shape, x0, acts, G, dz, weights)
+            dWs = [g if ctx.needs_input_grad[6 + j] else None for j, g in enumerate(dWs)]
+            dbs = [g if ctx.needs_input_grad[6 + L + j] else None for j, g in enumerate(dbs)]
+        return (d_xyz, d_feat, None, None, None, None, *dWs, *dbs)
+
+
+def fused_general_mlp_points(xyz: torch.Tensor, feat: Optional[torch.Tensor], multires: int, weights: Sequence[torch.Tensor],
+                             biases: Sequence[torch.Tensor], skips: Sequence[int] = (), negative_slope: float = 0.01,
+                             _shape: Optional[_Shape] = None) -> torch.Tensor:
+    """`fused_general_mlp(cat([positional_encoding(xyz, multires), feat]), ...)` with the input matrix built on the device in
+    one kernel: xyz [N, 3], feat [N, F] or None, float32 on a HIP device."""
+    _lib.load()
+    if not xyz.is_cuda:
+        raise RuntimeError("fused_general_mlp_points has no CPU path: tensors must be on a HIP ('cuda') device")
+    n_feat = 0 if feat is None else feat.shape[1]
+    d_in = 3 * (1 + 2 * max(multires, 0)) + n_feat
+    shape = _shape or _Shape(weights, d_in, skips)
+    if xyz.dim() != 2 or xyz.shape[1] != 3 or shape.d_in != d_in or (feat is not None and (feat.dim() != 2 or feat.shape[0] != xyz.shape[0])):
+        raise ValueError(f"xyz must be [N, 3] and feat [N, {shape.d_in - 3 * (1 + 2 * max(multires, 0))}]")
+    if xyz.dtype != torch.float32 or (feat is not None and (feat.dtype != torch.float32 or feat.device != xyz.device)):
+        raise ValueError("xyz and feat must be float32 tensors on the same device")
+    if not (0.0 <= negative_slope < 1.0) or len(biases) != shape.n_layers or len(weights) != shape.n_layers:
+        raise ValueError("negative_slope must be in [0, 1) and there must be one weight and one bias per layer")
+    if xyz.shape[0] == 0:
+        return xyz.new_zeros(0, shape.out_features) + 0.0 * (xyz.sum() + sum(w.sum() for w in weights) + sum(b.sum() for b in biases))
+    return _FusedMLPPointsFn.apply(xyz, feat, shape, float(negative_slope), int(max(multires, 0)), torch.is_grad_enabled(), *weights, *biases)
+
+
 def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], skips: Sequence[int] = (),
                       negative_slope: float = 0.01, _shape: Optional[_Shape] = None) -> torch.Tensor:
     """h_in [N, d_in] (positional encoding ++ features, as the reference builds it) -> [N, out_features]; differentiable with

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .fused_mlp import _Shape, fused_general_mlp
+from .fused_mlp import _Shape, fused_general_mlp, fused_general_mlp_points
 
 
 def positional_encoding(x: torch.Tensor, multires: int) -> torch.Tensor:
@@ -198,10 +198,16 @@ class GeneralMLP(nn.Module):
         return self._shape
 
     def forward(self, xyz: torch.Tensor, xyz_feat: Optional[torch.Tensor] = None, frame_id=None) -> torch.Tensor:
+        weights = compose_resfield_weights(list(self.net), frame_id)
+        biases = [layer.bias for layer in self.net]
+        if xyz.is_cuda and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.dtype == torch.float32 and \
+                (xyz_feat is None or (xyz_feat.dtype == torch.float32 and xyz_feat.dim() == 2)):
+            # the usual case: positions + features -> the padded input matrix in one kernel
+            h = fused_general_mlp_points(xyz, xyz_feat, self.multires, weights, biases, skips=self.skips, negative_slope=self.slope,
+                                         _shape=self._static_shape())
+            return self.out_act(h)
         h_in = positional_encoding(xyz, self.multires)
         if xyz_feat is not None:
             h_in = torch.cat([h_in, xyz_feat], dim=-1)
-        weights = compose_resfield_weights(list(self.net), frame_id)
-        biases = [layer.bias for layer in self.net]
         h = fused_general_mlp(h_in, weights, biases, skips=self.skips, negative_slope=self.slope, _shape=self._static_shape())
         return self.out_act(h)
