@@ -88,10 +88,17 @@ def main():
                             "mean_scale": None},
               "_source": "%s_pmc.json (rocprofv3 --pmc SQ_* passes of tools/profile.sh, means per launch)" % a.prefix,
               "_source_hash": source_hash()}
+        # average launch duration of the same kernels in the (counter-free) kernel-trace pass: kernel cycles / this = the clock
+        avg_ns = {}
+        for row in csv.DictReader(open(a.prefix + "_kernel_stats.csv")):
+            avg_ns[short_name(row["Name"])] = float(row["AverageNs"])
         for k, d in out.items():
             for prefix, s in (("sr::k_render_forward", "render_forward"), ("sr::k_render_backward", "render_backward")):
-                if k.startswith(prefix):
+                if k.startswith(prefix) and (s not in sq or d.get("SQ_WAVE_CYCLES_per_launch", 0) > sq[s].get("SQ_WAVE_CYCLES", 0)):
                     sq[s] = {c[:-len("_per_launch")]: v for c, v in d.items() if c.startswith("SQ_")}
+                    sq[s]["kernel"] = k
+                    if k in avg_ns:
+                        sq[s]["avg_launch_ns_kernel_trace"] = avg_ns[k]
         json.dump(sq, open(a.sq, "w"), indent=1, sort_keys=True)
 
     if a.traffic:
