@@ -413,11 +413,48 @@ __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Bin
     else sort_block_lds<2048, 256>(b, start, n, skey, [&](uint32_t rank, uint64_t key) { b.sorted_id[start + rank] = (uint32_t)key; });
 }
 
+// One merge pass in LDS: src[0, n) holds sorted runs of `width` entries (the last one may be short); adjacent pairs are
+// merged, out(position, key) receives every entry with its position after the pass.  Merge path: a thread produces E
+// consecutive outputs of its pair -- one binary search along the diagonal for where they start in the two runs
+// (log2(width) probes per THREAD), then E sequential compare-and-advance steps with one LDS read each.  (Ranking every
+// entry by its own binary search in the other run costs log2(width) dependent probes per ENTRY: a quarter to a third of the
+// whole sort at lists of 2000-3000 entries.)  Keys are unique.  E divides 2 * width.
+template <int E, typename Out>
+__device__ __forceinline__ void merge_run_pairs(const uint64_t* src, uint32_t n, uint32_t width, Out&& out) {
+    const uint32_t o = threadIdx.x * (uint32_t)E;  // first output of this thread
+    if (o >= n) return;
+    const uint32_t base = o & ~(2u * width - 1u);  // start of the pair
+    const uint64_t* A = src + base;                 // run B follows run A at A + width
+    const uint32_t a = min(width, n - base);
+    const uint32_t b = n - base - a < width ? n - base - a : width;
+    const uint32_t d = o - base;                    // outputs of the pair before this thread's
+    uint32_t lo = d > b ? d - b : 0u, hi = min(d, a);
+    while (lo < hi) {                               // smallest ai with A[ai] > B[d - 1 - ai]
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] < A[width + d - 1u - mid]) lo = mid + 1u; else hi = mid;
+    }
+    uint32_t ai = lo, bi = d - lo;
+    constexpr uint64_t kInf = ~0ull;
+    uint64_t ka = ai < a ? A[ai] : kInf;
+    uint64_t kb = bi < b ? A[width + bi] : kInf;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool take_a = ka < kb;
+        const uint64_t key = take_a ? ka : kb;
+        if (d + (uint32_t)e < a + b) out(o + (uint32_t)e, key);
+        ai += take_a ? 1u : 0u;
+        bi += take_a ? 0u : 1u;
+        const bool more = take_a ? ai < a : bi < b;
+        const uint64_t nxt = A[take_a ? min(ai, a - 1u) : width + min(bi, max(b, 1u) - 1u)];
+        if (take_a) ka = more ? nxt : kInf; else kb = more ? nxt : kInf;
+    }
+}
+
 // Sorts n <= CAP entries starting at b.ent[first]: runs of 1024 are sorted by the register network into LDS (one
-// 256-thread group per run, side by side), then ONE multi-way merge pass -- keys are unique, so the final position of an
-// entry is its index in its own run plus, for every other run, the number of smaller keys there (binary search in LDS).
-// A list of 1100 entries costs a 1024- and a 256-network instead of the 2048-network of a power-of-two bitonic sort.
-// emit(rank, key) receives every entry with its final rank.  Ends with a workgroup barrier.
+// 256-thread group per run, side by side), then merged pairwise (merge_run_pairs) until one run is left.  A list of 1100
+// entries costs a 1024- and a 256-network instead of the 2048-network of a power-of-two bitonic sort.
+// emit(rank, key) receives every entry with its final rank.  run_key: CAP entries, + CAP more when n > 2048.
+// Ends with a workgroup barrier.
 template <int CAP, int THREADS, typename Emit>
 __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, Emit&& emit) {
     constexpr int GROUPS = THREADS / 256;
@@ -453,23 +490,23 @@ __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first,
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-        const uint32_t own = i >> 10;
-        const uint64_t key = run_key[i];
-        uint32_t rank = i & 1023u;
-        for (uint32_t r = 0; r < n_runs; ++r) {
-            if (r == own) continue;
-            const uint64_t* rk = run_key + r * 1024u;
-            uint32_t lo = 0, hi = min(1024u, n - r * 1024u);
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rk[mid] < key) lo = mid + 1; else hi = mid; }
-            rank += lo;
+    // Pairwise merge passes over the runs (1024 -> 2048 -> ...); the last one hands the entries to emit().  Lists of up
+    // to 2048 entries (two runs) need one pass and no second buffer; longer ones ping-pong with run_key + CAP.
+    uint64_t* src = run_key;
+    uint64_t* dst = run_key + CAP;
+    for (uint32_t width = 1024u;; width <<= 1) {
+        if (2u * width >= n) {
+            merge_run_pairs<CAP / THREADS>(src, n, width, emit);
+            break;
         }
-        emit(rank, key);
+        merge_run_pairs<CAP / THREADS>(src, n, width, [&](uint32_t pos, uint64_t key) { dst[pos] = key; });
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
     }
     __syncthreads();
 }
 
-// lists of (LO, CAP] entries, one workgroup per tile; LDS = CAP * 8 bytes
+// lists of (LO, CAP] entries, one workgroup per tile; LDS = CAP * 16 bytes (runs + merge ping-pong buffer)
 template <int LO, int CAP, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, const Binning b, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -536,7 +573,7 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    auto lds = [](int cap, int) { return (size_t)cap * 8; };
+    auto lds = [](int cap, int) { return (size_t)cap * 16; };   // the runs + the ping-pong buffer of the merge passes
     hipLaunchKernelGGL(k_sort_tiles_regs, dim3(tiles), dim3(256), 0, st, g, b);   // every list of up to 2048 entries
     if (max_len >= 0 && max_len <= 2048) return;
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), 2, (int)lds(4096, 1024));
