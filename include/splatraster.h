@@ -250,6 +250,8 @@ typedef struct SrMlpOp {
     const float* src;          /* memory input channels (mem_tiles > 0) */
     const float* mask;         /* SR_MLP_MASK */
     float* store;              /* may be null */
+    unsigned int* sign_store;  /* may be null: word [point * 4 + k], bit 4 t + i = (result channel 16 t + 4 k + i > 0) */
+    const unsigned int* mask_bits; /* SR_MLP_MASK: if set, leaky'(.) comes from these bits (the layout sign_store writes) instead of `mask` */
     int out_tiles;
     int mem_tiles;             /* even */
     int reg_tiles;             /* even */

@@ -35,6 +35,7 @@ class SrGrads(C.Structure):
 
 class SrMlpOp(C.Structure):
     _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("src", C.c_void_p), ("mask", C.c_void_p), ("store", C.c_void_p),
+                ("sign_store", C.c_void_p), ("mask_bits", C.c_void_p),
                 ("out_tiles", C.c_int), ("mem_tiles", C.c_int), ("reg_tiles", C.c_int), ("src_row", C.c_int), ("epilogue", C.c_int),
                 ("mask_row", C.c_int), ("store_row", C.c_int), ("store_channels", C.c_int), ("store_accumulate", C.c_int),
                 ("keep_state", C.c_int)]

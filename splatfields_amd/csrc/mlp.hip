@@ -114,6 +114,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
             if (L.bias && mt < L.out_tiles) { const float4 t4 = reinterpret_cast<const float4*>(L.bias)[4 * mt + k]; b4 = (f32x4){t4.x, t4.y, t4.z, t4.w}; }
             acc[0][mt] = b4; acc[1][mt] = b4;
         }
+        // backward: leaky'(.) of the layer below as one bit per channel (written by the forward's sign_store): one dword per
+        // point tile, requested here and used in the epilogue, instead of the 16 float4 of the saved activations themselves
+        uint32_t mbits[2] = {0u, 0u};
+        if (L.mask_bits) { mbits[0] = L.mask_bits[(size_t)prow[0] * 4 + k]; mbits[1] = L.mask_bits[(size_t)prow[1] * 4 + k]; }
         __syncthreads();          // everyone has left the previous op's last chunk
         stage(0, buf);
         int c = 0;
@@ -157,7 +161,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
         }
         // ---- epilogue: channel 16 mt + 4 k + i of point (nt, n) ----
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+            uint32_t signs = 0u;                                // bit 4 mt + i: channel 16 mt + 4 k + i of this point is > 0
 #pragma unroll
             for (int mt = 0; mt < HT; ++mt) {
                 f32x4 r = {0.f, 0.f, 0.f, 0.f};
@@ -167,9 +172,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], slope * r[i]);
                     } else if (L.epilogue == SR_MLP_MASK) {      // backward: times leaky'(x), read off the saved activation's sign
-                        const float4 m4 = *reinterpret_cast<const float4*>(L.mask + (size_t)prow[nt] * L.mask_row + 16 * mt + 4 * k);
-                        r[0] *= m4.x > 0.f ? 1.0f : slope; r[1] *= m4.y > 0.f ? 1.0f : slope;
-                        r[2] *= m4.z > 0.f ? 1.0f : slope; r[3] *= m4.w > 0.f ? 1.0f : slope;
+                        if (L.mask_bits) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) r[i] *= (mbits[nt] >> (4 * mt + i)) & 1u ? 1.0f : slope;
+                        } else {
+                            const float4 m4 = *reinterpret_cast<const float4*>(L.mask + (size_t)prow[nt] * L.mask_row + 16 * mt + 4 * k);
+                            r[0] *= m4.x > 0.f ? 1.0f : slope; r[1] *= m4.y > 0.f ? 1.0f : slope;
+                            r[2] *= m4.z > 0.f ? 1.0f : slope; r[3] *= m4.w > 0.f ? 1.0f : slope;
+                        }
+                    }
+                    if (L.sign_store) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) signs |= (r[i] > 0.f ? 1u : 0u) << (4 * mt + i);
                     }
                     if (L.store && pvalid[nt]) {
                         float* dst = L.store + (size_t)(p0 + 16 * nt + n) * L.store_row + 16 * mt + 4 * k;
@@ -186,6 +200,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
                 }
                 if (!L.keep_state) prev[nt][mt] = r;
             }
+            if (L.sign_store && pvalid[nt]) L.sign_store[(size_t)(p0 + 16 * nt + n) * 4 + k] = signs;
+        }
     }
 }
 
@@ -296,25 +312,39 @@ __global__ void __launch_bounds__(kBlock) k_mlp_weight_grad(const MlpGradK P) {
     }
 }
 
+// Adds the partial blocks over the slabs in a FIXED order: a workgroup owns 64 consecutive entries of a task's block (or its
+// 64 bias entries); wavefront q adds slabs q, q + 4, q + 8, ... (eight loads in flight), the four partial sums are added in
+// order q = 0..3.  (One thread per entry walking all 256 slabs kept a 48 x 48 gradient waiting 65 us on 17 workgroups.)
 __global__ void __launch_bounds__(kBlock) k_mlp_weight_grad_reduce(const MlpGradK P) {
+    __shared__ float s_part[4][64];
     const int t = blockIdx.y;
     const GradTask T = P.task[t];
     const SrMlpGradJob J = P.job[T.job];
-    const int e = blockIdx.x * kBlock + (int)threadIdx.x;
-    if (e < 4096) {
-        const int m = 64 * T.bm + (e >> 6), c = 64 * T.bk + (e & 63);
-        if (m >= J.m || c >= J.k) return;
-        const float* src = P.part + (size_t)t * P.n_slabs * 4096 + e;
-        float sum = 0.0f;
-        for (int s = 0; s < P.n_slabs; ++s) sum += src[(size_t)s * 4096];
-        J.dw[(size_t)m * J.dw_row + J.dw_col0 + c] = sum;
-    } else if (e < 4096 + 64 && T.bias) {
+    const int q = wave_id(), e = blockIdx.x * 64 + lane_id();
+    const bool bias_row = e >= 4096;
+    if (bias_row && !T.bias) return;                  // block-uniform
+    const float* src = bias_row ? P.bias_part + (size_t)t * P.n_slabs * 64 + (e - 4096) : P.part + (size_t)t * P.n_slabs * 4096 + e;
+    const size_t stride = bias_row ? 64 : 4096;
+    float sum = 0.0f;
+    int sl = q;
+    for (; sl + 28 < P.n_slabs; sl += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sl + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; sl < P.n_slabs; sl += 4) sum += src[(size_t)sl * stride];
+    s_part[q][lane_id()] = sum;
+    __syncthreads();
+    if (q != 0) return;
+    sum = ((s_part[0][lane_id()] + s_part[1][lane_id()]) + s_part[2][lane_id()]) + s_part[3][lane_id()];
+    if (bias_row) {
         const int m = 64 * T.bm + (e - 4096);
-        if (m >= J.m) return;
-        const float* src = P.bias_part + (size_t)t * P.n_slabs * 64 + (e - 4096);
-        float sum = 0.0f;
-        for (int s = 0; s < P.n_slabs; ++s) sum += src[(size_t)s * 64];
-        J.db[m] = sum;
+        if (m < J.m) J.db[m] = sum;
+    } else {
+        const int m = 64 * T.bm + (e >> 6), c = 64 * T.bk + (e & 63);
+        if (m < J.m && c < J.k) J.dw[(size_t)m * J.dw_row + J.dw_col0 + c] = sum;
     }
 }
 
@@ -365,7 +395,7 @@ int launch_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, v
     k.part = static_cast<float*>(workspace);
     k.bias_part = k.part + (size_t)nt * k.n_slabs * 4096;
     hipLaunchKernelGGL(k_mlp_weight_grad, dim3(k.n_slabs, (nt + 3) / 4), dim3(kBlock), 0, st, k);
-    hipLaunchKernelGGL(k_mlp_weight_grad_reduce, dim3((4096 + 64 + kBlock - 1) / kBlock, nt), dim3(kBlock), 0, st, k);
+    hipLaunchKernelGGL(k_mlp_weight_grad_reduce, dim3((4096 + 64) / 64, nt), dim3(kBlock), 0, st, k);
     return 0;
 }
 
@@ -399,7 +429,8 @@ int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* o
             (reinterpret_cast<uintptr_t>(s.w_packed) & 15u) || (reinterpret_cast<uintptr_t>(s.bias) & 15u)) return 1;
         if (s.mem_tiles > 0 && (!s.src || s.mem_tiles * 16 > s.src_row || (s.src_row & 3) || (reinterpret_cast<uintptr_t>(s.src) & 15u))) return 1;
         if (s.epilogue != SR_MLP_NONE && s.epilogue != SR_MLP_LEAKY && s.epilogue != SR_MLP_MASK) return 1;
-        if (s.epilogue == SR_MLP_MASK && (!s.mask || s.out_tiles * 16 > s.mask_row || (s.mask_row & 3) || (reinterpret_cast<uintptr_t>(s.mask) & 15u))) return 1;
+        if (s.epilogue == SR_MLP_MASK && !s.mask_bits && (!s.mask || s.out_tiles * 16 > s.mask_row || (s.mask_row & 3) || (reinterpret_cast<uintptr_t>(s.mask) & 15u))) return 1;
+        if ((reinterpret_cast<uintptr_t>(s.mask_bits) & 3u) || (reinterpret_cast<uintptr_t>(s.sign_store) & 3u)) return 1;
         if (s.store && (s.store_channels < 1 || s.store_channels > s.store_row || s.store_channels > 16 * s.out_tiles)) return 1;
         net.op[l] = s;
     }

@@ -26,6 +26,7 @@ from typing import Optional
 import torch
 from torch import nn
 
+from .fused_mlp import PointLinear
 from .general_mlp import GeneralMLP, positional_encoding
 
 
@@ -63,12 +64,12 @@ class FlowHead(nn.Module):
         super().__init__()
         self.W, self.flow_model, self.n_frames, self.num_basis = W, flow_model, n_frames, num_basis
         if flow_model == "offset":
-            self.gaussian_warp = nn.Linear(W, 3)
+            self.gaussian_warp = PointLinear(W, 3)
         elif flow_model == "se3":
-            self.branch_w = nn.Linear(W, 3)
-            self.branch_v = nn.Linear(W, 3)
+            self.branch_w = PointLinear(W, 3)
+            self.branch_v = PointLinear(W, 3)
         elif flow_model == "dct":
-            self.branch_coeff = nn.Linear(W, 3 * num_basis)
+            self.branch_coeff = PointLinear(W, 3 * num_basis)
             nn.init.zeros_(self.branch_coeff.weight)
             nn.init.zeros_(self.branch_coeff.bias)
             self.trajectory_basis = nn.Parameter(dct_basis(num_basis, n_frames * 2))
@@ -107,7 +108,7 @@ class SplatFields(nn.Module):
         if encoder is not None:
             self.encoder = encoder
             self.feat_dim = int(encoder.out_dim)
-            self.mlp_refine_feat = nn.Sequential(nn.Linear(self.feat_dim, self.feat_dim), nn.ReLU(), nn.Linear(self.feat_dim, self.feat_dim))
+            self.mlp_refine_feat = nn.Sequential(PointLinear(self.feat_dim, self.feat_dim), nn.ReLU(), PointLinear(self.feat_dim, self.feat_dim))
         else:
             self.feat_dim = 0
         if n_frames > 0:

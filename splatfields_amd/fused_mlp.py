@@ -72,7 +72,7 @@ class _Shape:
         self.plans: dict = {}     # descriptor arrays of the forward / backward / weight-gradient launches, built on first use
 
 
-_PACK_PTRS, _OP_PTRS = ("w", "bias_src"), ("src", "mask", "store")
+_PACK_PTRS, _OP_PTRS = ("w", "bias_src"), ("src", "mask", "store", "sign_store", "mask_bits")
 
 
 class _Plan:
@@ -152,28 +152,31 @@ def _forward_plan(shape: _Shape, save: bool) -> _Plan:
             op = dict(epilogue=_lib.MLP_LEAKY, src=("x0", 0, 0) if n_mem else None, src_row=shape.mem_pad)
             if last:
                 op.update(store=("y", 0, 0), store_row=shape.out_features, store_channels=shape.out_features)
-            elif save:
-                op.update(store=("acts", j, 0), store_row=H, store_channels=H)
+            elif save:       # the activation itself (an operand of dW of the layer above) and its signs (leaky' for the backward chain)
+                op.update(store=("acts", j, 0), store_row=H, store_channels=H, sign_store=("signs", j, 0))
             b.add(job, op, with_bias=True)
         shape.plans[key] = b
     return shape.plans[key]
 
 
 def _forward(shape: _Shape, x0: torch.Tensor, weights, biases, slope: float, save: bool):
-    """x0 [N, mem_pad] -> (y [N, out], acts [L-1, N, hidden] or None)."""
+    """x0 [N, mem_pad] -> (y [N, out], acts [L-1, N, hidden] or None, signs [L-1, N, 4] int32 or None: one bit per activation,
+    set where it is > 0, in the layout of SrMlpOp.sign_store)."""
     lib = _lib.load()
     dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
     y = torch.empty(n, shape.out_features, dtype=torch.float32, device=dev)
     acts = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev) if save else None
+    signs = torch.empty(L - 1, n, 4, dtype=torch.int32, device=dev) if save else None
     ptrs = {"W": [w.data_ptr() for w in weights], "B": [b_.data_ptr() for b_ in biases], "x0": (x0.data_ptr(),), "y": (y.data_ptr(),),
-            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)] if save else ()}
+            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)] if save else (),
+            "signs": [signs.data_ptr() + 16 * j * n for j in range(L - 1)] if save else ()}
     with torch.cuda.device(dev):
         _forward_plan(shape, save).run(lib, ptrs, dev, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
-    return y, acts
+    return y, acts, signs
 
 
-def _backward_plan(shape: _Shape, need_input: bool) -> _Plan:
-    key = ("bwd", need_input)
+def _backward_plan(shape: _Shape, need_input: bool, bits: bool) -> _Plan:
+    key = ("bwd", need_input, bits)
     if key not in shape.plans:
         H, L = shape.hidden, shape.n_layers
         b = _Plan()
@@ -194,15 +197,16 @@ def _backward_plan(shape: _Shape, need_input: bool) -> _Plan:
                     b.add(job, op, with_bias=False)
             if j > 0:                                                   # dZ_{j-1} = (W_j[:, hidden block]^T dZ_j) * act'(h_{j-1})
                 job = dict(w=("W", j, 0), ld=ld, transposed=1, row0=n_mem_w, n_rows=H, out_tiles=shape.ht, **cols)
-                op = dict(epilogue=_lib.MLP_MASK, mask=("acts", j - 1, 0), mask_row=H, store=("dz", j - 1, 0), store_row=H,
-                          store_channels=H, **src)
+                mask = dict(mask_bits=("signs", j - 1, 0)) if bits else dict(mask=("acts", j - 1, 0), mask_row=H)
+                op = dict(epilogue=_lib.MLP_MASK, store=("dz", j - 1, 0), store_row=H, store_channels=H, **mask, **src)
                 b.add(job, op, with_bias=False)
         shape.plans[key] = b
     return shape.plans[key]
 
 
-def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input: bool):
-    """-> (dL/dx0 [N, mem_pad] or None, G [N, out_pad] = dZ of the last layer (zero-padded), dz [L-1, N, hidden] = dZ of the others)."""
+def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input: bool, signs=None):
+    """-> (dL/dx0 [N, mem_pad] or None, G [N, out_pad] = dZ of the last layer (zero-padded), dz [L-1, N, hidden] = dZ of the others).
+    leaky'(.) of the hidden layers is read off `signs` (16 bytes per point and layer) when given, else off `acts` (4 * hidden)."""
     lib = _lib.load()
     dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
     gz = dY * torch.where(y > 0, 1.0, slope)
@@ -210,9 +214,10 @@ def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input:
     dz = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev)
     dx0 = torch.zeros(n, shape.mem_pad, dtype=torch.float32, device=dev) if need_input else None
     ptrs = {"W": [w.data_ptr() for w in weights], "G": (G.data_ptr(),), "dx0": (dx0.data_ptr() if need_input else 0,),
-            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)], "dz": [dz.data_ptr() + 4 * j * n * H for j in range(L - 1)]}
+            "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)], "dz": [dz.data_ptr() + 4 * j * n * H for j in range(L - 1)],
+            "signs": [signs.data_ptr() + 16 * j * n for j in range(L - 1)] if signs is not None else ()}
     with torch.cuda.device(dev):
-        _backward_plan(shape, need_input).run(lib, ptrs, dev, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
+        _backward_plan(shape, need_input, signs is not None).run(lib, ptrs, dev, n, shape.ht, slope, torch.cuda.current_stream(dev).cuda_stream)
     return dx0, G, dz
 
 
@@ -290,20 +295,20 @@ class _FusedMLPFn(torch.autograd.Function):
         # needs_input_grad reflects requires_grad of the inputs, not the grad mode (inside forward() grad mode is always off):
         # under torch.no_grad() nothing will run backward, so the [L-1, N, hidden] activation stack is neither allocated nor written
         need = grad_enabled and any(ctx.needs_input_grad)
-        y, acts = _forward(shape, x0, weights, biases, slope, save=need)
+        y, acts, signs = _forward(shape, x0, weights, biases, slope, save=need)
         if need:
             ctx.shape, ctx.slope = shape, slope
-            ctx.save_for_backward(x0, acts, y, *weights)
+            ctx.save_for_backward(x0, acts, signs, y, *weights)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dY):
         shape, slope = ctx.shape, ctx.slope
-        x0, acts, y, *weights = ctx.saved_tensors
+        x0, acts, signs, y, *weights = ctx.saved_tensors
         L, d_in = shape.n_layers, shape.d_in
         need_input = ctx.needs_input_grad[0]
-        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_input)
+        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_input, signs)
         dWs, dbs = [None] * L, [None] * L
         if any(ctx.needs_input_grad[4:]):
             dWs, dbs = _weight_grads(shape, x0, acts, G, dz, weights)
@@ -334,10 +339,10 @@ class _FusedMLPPointsFn(torch.autograd.Function):
                                                 C.c_void_p(f32.data_ptr()) if f32 is not None else None, C.c_void_p(x0.data_ptr()),
                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         need = grad_enabled and any(ctx.needs_input_grad)
-        y, acts = _forward(shape, x0, weights, biases, slope, save=need)
+        y, acts, signs = _forward(shape, x0, weights, biases, slope, save=need)
         if need:
             ctx.shape, ctx.slope, ctx.multires, ctx.n_feat = shape, slope, multires, n_feat
-            ctx.save_for_backward(x32, x0, acts, y, *weights)
+            ctx.save_for_backward(x32, x0, acts, signs, y, *weights)
         return y
 
     @staticmethod
@@ -345,10 +350,10 @@ class _FusedMLPPointsFn(torch.autograd.Function):
     def backward(ctx, dY):
         lib = _lib.load()
         shape, slope = ctx.shape, ctx.slope
-        x32, x0, acts, y, *weights = ctx.saved_tensors
+        x32, x0, acts, signs, y, *weights = ctx.saved_tensors
         L, dev, n = shape.n_layers, x0.device, x0.shape[0]
         need_xyz, need_feat = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.n_feat > 0
-        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_xyz or need_feat)
+        dx0, G, dz = _backward(shape, x0, acts, y, dY.to(torch.float32).contiguous(), weights, slope, need_xyz or need_feat, signs)
         d_xyz = torch.empty(n, 3, dtype=torch.float32, device=dev) if need_xyz else None
         d_feat = torch.empty(n, ctx.n_feat, dtype=torch.float32, device=dev) if need_feat else None
         if need_xyz or need_feat:
@@ -413,6 +418,74 @@ def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biase
     if h_in.shape[0] == 0:      # nothing to launch; keep the graph connected so that parameters still receive (zero) gradients
         return h_in.new_zeros(0, shape.out_features) + 0.0 * (h_in.sum() + sum(w.sum() for w in weights) + sum(b.sum() for b in biases))
     return _FusedMLPFn.apply(h_in, shape, float(negative_slope), torch.is_grad_enabled(), *weights, *biases)
+
+
+class _PointLinearFn(torch.autograd.Function):
+    """y = x W^T + b for a tall matrix of per-point rows ([N, in], N ~ 10^5, in and out a few dozen): the products with the
+    weight are library GEMMs, but dL/dW = dY^T x and dL/db = column sums of dY contract over the POINTS -- the shape library
+    GEMMs and reductions serialise (0.29 ms per 48 x 48 x 100k product and 0.14 ms per bias on MI355X; the tri-plane refine MLP
+    and the flow head were 1.4 ms of an 8.5 ms network step) -- and go through the slab kernel of the fused MLPs
+    (sr_mlp_weight_grad: deterministic, ~0.03 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dY):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        dev, n, m, k = x.device, x.shape[0], W.shape[0], W.shape[1]
+        need_x, need_W = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dY = dY.contiguous()
+        dX = dY @ W if need_x else None
+        dW = db = None
+        if need_W or need_b:
+            m_pad = (m + 3) // 4 * 4
+            dz = dY if m_pad == m else F.pad(dY, (0, m_pad - m))
+            dW = torch.empty_like(W)
+            db = torch.empty(m, dtype=torch.float32, device=dev)
+            job = (_lib.SrMlpGradJob * 1)()
+            job[0].dz_row, job[0].m, job[0].x_row, job[0].k, job[0].dw_row, job[0].dw_col0 = m_pad, m, k, k, k, 0
+            n_max = max(64, ((1 << 31) - 1) // (4 * max(m_pad, k)) // 64 * 64)
+            for lo in range(0, n, n_max):
+                cnt = min(n_max, n - lo)
+                pW, pb = (dW, db) if lo == 0 else (torch.empty_like(W), torch.empty_like(db))
+                job[0].dz, job[0].x = dz.data_ptr() + 4 * lo * m_pad, x.data_ptr() + 4 * lo * k
+                job[0].dw, job[0].db = pW.data_ptr(), pb.data_ptr()
+                ws_bytes = lib.sr_mlp_weight_grad_workspace(cnt, 1, job)
+                if ws_bytes == 0:
+                    raise ValueError("unsupported weight-gradient job: " + lib.sr_last_error().decode("utf-8", "replace"))
+                ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.sr_mlp_weight_grad(cnt, 1, job, C.c_void_p(ws.data_ptr()), ws_bytes,
+                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                if lo:
+                    dW.add_(pW)
+                    db.add_(pb)
+        return dX, (dW if need_W else None), (db if need_b else None)
+
+
+def point_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`F.linear(x, weight, bias)` for per-point rows x [N, in]; on a HIP device (float32, in a multiple of 4) the weight and
+    bias gradients come from the fused MLPs' slab kernel instead of a library GEMM over N (see _PointLinearFn)."""
+    ok = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[1] % 4 == 0 and \
+        x.shape[0] > 0 and weight.device == x.device and (bias is None or (bias.dtype == torch.float32 and bias.device == x.device)) and \
+        weight.shape[0] <= 64 * 255 and weight.shape[1] <= 64 * 255
+    if not ok or not (torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))):
+        return F.linear(x, weight, bias)
+    return _PointLinearFn.apply(x.contiguous(), weight.contiguous(), bias)
+
+
+class PointLinear(torch.nn.Linear):
+    """`nn.Linear` (same parameters, initialisation and state-dict keys) applied to per-point rows through `point_linear`."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return point_linear(x, self.weight, self.bias)
 
 
 class FusedGeneralMLP:

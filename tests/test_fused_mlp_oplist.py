@@ -17,6 +17,17 @@ def view(ptr, rows, row, cols):
     t = torch.frombuffer(arr, dtype=torch.float32)
     return torch.as_strided(t, (rows, cols), (row, 1))
 
+def bit_view(ptr, rows):
+    arr = (ctypes.c_int32 * (4 * rows)).from_address(ptr)
+    return torch.frombuffer(arr, dtype=torch.int32).view(rows, 4)
+
+
+def channel_bit_index(channels):
+    """SrMlpOp.sign_store / mask_bits (include/splatraster.h): channel 16 t + 4 k + i  <->  word k, bit 4 t + i"""
+    c = torch.arange(channels)
+    return (c % 16) // 4, 4 * (c // 16) + c % 4
+
+
 def job_matrix(job):
     K = job["n_mem"] + job["n_reg"]
     ld = job["ld"]
@@ -42,7 +53,7 @@ def interpret(self, lib, ptrs, device, n, ht, slope, stream):
         return {k: (ptrs[v[0]][v[1]] + v[2] if (k in keys and v is not None) else v) for k, v in d.items()}
     state = torch.zeros(n, 16 * ht)
     for job, op in zip(self.jobs, self.ops):
-        job, op = resolved(job, ("w", "bias")), resolved(op, ("src", "mask", "store"))
+        job, op = resolved(job, ("w", "bias")), resolved(op, ("src", "mask", "store", "sign_store", "mask_bits"))
         A = job_matrix(job)
         mem_t, reg_t = job["mem_pad"], job["reg_width"]
         parts = []
@@ -56,8 +67,17 @@ def interpret(self, lib, ptrs, device, n, ht, slope, stream):
         ep = op["epilogue"]
         if ep == 1: acc = torch.maximum(acc, slope * acc)
         elif ep == 2:
-            m = view(op["mask"], n, op["mask_row"], acc.shape[1])
+            if op.get("mask_bits"):
+                word, bit = channel_bit_index(acc.shape[1])
+                m = (bit_view(op["mask_bits"], n)[:, word] >> bit) & 1
+            else:
+                m = view(op["mask"], n, op["mask_row"], acc.shape[1])
             acc = acc * torch.where(m > 0, 1.0, slope)
+        if op.get("sign_store"):
+            word, bit = channel_bit_index(acc.shape[1])
+            words = torch.zeros(n, 4, dtype=torch.int64)
+            words.index_add_(1, word, (acc > 0).to(torch.int64) << bit)
+            bit_view(op["sign_store"], n).copy_(words.to(torch.int32))
         if op.get("store"):
             dst = view(op["store"], n, op["store_row"], op["store_channels"])
             if op.get("store_accumulate"): dst += acc[:, :op["store_channels"]]
@@ -96,8 +116,10 @@ def test_op_lists_compute_the_network_and_its_gradients(monkeypatch, d_in, H, nh
     h_in, dY = torch.randn(n, d_in, generator=g), torch.randn(n, out, generator=g)
     shape = fm._Shape(ws, d_in, skips)
     x0 = F.pad(h_in, (0, shape.mem_pad - d_in)).contiguous()
-    y, acts = fm._forward(shape, x0, ws, bs, 0.05, True)
-    dx0, G, dz = fm._backward(shape, x0, acts, y, dY, ws, 0.05, True)
+    y, acts, signs = fm._forward(shape, x0, ws, bs, 0.05, True)
+    dx0, G, dz = fm._backward(shape, x0, acts, y, dY, ws, 0.05, True, signs)
+    dx0_f, G_f, dz_f = fm._backward(shape, x0, acts, y, dY, ws, 0.05, True)        # leaky' read off the activations themselves
+    assert torch.equal(dx0, dx0_f) and torch.equal(dz, dz_f)
     hr = h_in.double().requires_grad_()
     wr, br = [w.double().requires_grad_() for w in ws], [b.double().requires_grad_() for b in bs]
     yr = reference(hr, wr, br, set(skips), 0.05)

@@ -295,3 +295,54 @@ def test_resfield_composition_kernel(hip_device):
         err = (g1[k] - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), 1e-12)
         assert err <= 2e-5, (k, err)
     assert (g1["1.weights_t"][torch.arange(100, device=dev) != 37] == 0).all()    # only the frame's row receives a gradient
+
+
+@pytest.mark.parametrize("n,k,m", [(100_000, 48, 48), (5000, 128, 3), (777, 128, 12), (64, 48, 48)])
+def test_point_linear_gradients_match_float64(hip_device, n, k, m):
+    """PointLinear (tri-plane refine MLP, flow head: reference utils/time_utils.py:331-333, :78-113) = nn.Linear whose weight and
+    bias gradients come from the slab kernel: output identical to F.linear, gradients against float64 autograd <= 1e-5 of each
+    tensor's largest entry, and bit-reproducible."""
+    from splatfields_amd.fused_mlp import PointLinear
+    dev = hip_device
+    torch.manual_seed(n + k + m)
+    lin = PointLinear(k, m).to(dev)
+    x = torch.randn(n, k, device=dev, requires_grad=True)
+    g = torch.randn(n, m, device=dev)
+    y = lin(x)
+    assert torch.equal(y, F.linear(x, lin.weight, lin.bias))
+    y.backward(g)
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x64 = x.detach().double().requires_grad_(True)
+    W64, b64 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    F.linear(x64, W64, b64).backward(g.double())
+    for a, b in zip(got, (x64.grad, W64.grad, b64.grad)):
+        assert ((a.double() - b).abs().max() / b.abs().max()).item() < 1e-5
+    x.grad = None
+    lin.zero_grad(set_to_none=True)
+    lin(x).backward(g)
+    assert torch.equal(lin.weight.grad, got[1]) and torch.equal(lin.bias.grad, got[2])
+    with torch.no_grad():                       # nothing to save, the plain library call
+        assert torch.equal(lin(x), y)
+
+
+@pytest.mark.parametrize("d_in,hidden,n_hidden,skips,out", [(94, 128, 6, [3], 3), (82, 64, 4, [2], 3)])
+@pytest.mark.parametrize("slope", [0.01, 0.0])
+def test_sign_bits_carry_the_activation_derivative(hip_device, d_in, hidden, n_hidden, skips, out, slope):
+    """The forward writes one bit per saved activation (SrMlpOp.sign_store, include/splatraster.h); the backward chain reads
+    leaky'(.) off those bits instead of the activations: same words as `acts > 0`, and bit-identical dZ / dL/dx0 to the chain
+    that masks with the float activations."""
+    from splatfields_amd import fused_mlp as fm
+    dev = hip_device
+    n = 3000
+    weights, biases = make_net(d_in, hidden, n_hidden, skips, out, dev, 11)
+    g = torch.Generator().manual_seed(5)
+    shape = fm._Shape(weights, d_in, skips)
+    x0 = F.pad(torch.randn(n, d_in, generator=g), (0, shape.mem_pad - d_in)).to(dev).contiguous()
+    dY = torch.randn(n, out, generator=g).to(dev)
+    y, acts, signs = fm._forward(shape, x0, weights, biases, slope, True)
+    c = torch.arange(hidden, device=dev)
+    word, bit = (c % 16) // 4, 4 * (c // 16) + c % 4
+    assert torch.equal(((signs[:, :, word] >> bit) & 1).bool(), acts > 0)
+    a = fm._backward(shape, x0, acts, y, dY, weights, slope, True, signs)
+    b = fm._backward(shape, x0, acts, y, dY, weights, slope, True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -62,10 +62,11 @@ def main():
         res["torch_fwd_ms"] = timed(lambda: ref(h_in))
         res["fused_fwd_nosave_ms"] = timed(lambda: fm._forward(shape, x0, wd, bd, 0.01, save=False))
         res["fused_fwd_save_ms"] = timed(lambda: fm._forward(shape, x0, wd, bd, 0.01, save=True))
-        y, acts = fm._forward(shape, x0, wd, bd, 0.01, save=True)
-        res["fused_bwd_chain_ms"] = timed(lambda: fm._backward(shape, x0, acts, y, dY, wd, 0.01, True))
-        res["fused_bwd_chain_noinput_ms"] = timed(lambda: fm._backward(shape, x0, acts, y, dY, wd, 0.01, False))
-        dx0, gz, dz = fm._backward(shape, x0, acts, y, dY, wd, 0.01, True)
+        y, acts, signs = fm._forward(shape, x0, wd, bd, 0.01, save=True)
+        res["fused_bwd_chain_ms"] = timed(lambda: fm._backward(shape, x0, acts, y, dY, wd, 0.01, True, signs))
+        res["fused_bwd_chain_float_masks_ms"] = timed(lambda: fm._backward(shape, x0, acts, y, dY, wd, 0.01, True))
+        res["fused_bwd_chain_noinput_ms"] = timed(lambda: fm._backward(shape, x0, acts, y, dY, wd, 0.01, False, signs))
+        dx0, gz, dz = fm._backward(shape, x0, acts, y, dY, wd, 0.01, True, signs)
 
         def dws():
             out = []
