@@ -38,10 +38,11 @@ struct MlpK { int n_ops; SrMlpOp op[kMlpMaxOps]; };
 
 // One 16-channel input tile (4 MFMA K steps) against all output tiles.  `w` points at this lane's float4 of output tile 0
 // (consecutive output tiles are 128 float4 apart).  FULL (every one of the HT output tiles is live, the common case): the LDS
-// reads of four output tiles are issued together and the MFMAs rotate over eight accumulators, so neither the LDS latency
+// reads of SR_MLP_GROUP output tiles are issued together and the MFMAs rotate over twice as many accumulators, so neither the LDS latency
 // nor the dependent accumulate chains stall the matrix pipe; otherwise tile by tile under a wave-uniform test.
 #ifndef SR_MLP_GROUP
-#define SR_MLP_GROUP 4      // output tiles whose LDS reads are issued together (the MFMAs rotate over 2 x this many accumulators)
+#define SR_MLP_GROUP 2      // output tiles whose LDS reads are issued together (the MFMAs rotate over 2 x this many accumulators);
+                            // 4 costs 8 more registers at the 256-register ceiling of the 128-wide kernel: measured 3-5 % slower
 #endif
 #ifndef SR_MLP_WAVES8
 #define SR_MLP_WAVES8 2     // wavefronts per SIMD the 128-wide kernel is compiled for (256 / 168 VGPRs)
@@ -78,6 +79,40 @@ __device__ __forceinline__ void mlp_tile(f32x4 (&acc)[2][HT], const float4* w, i
                 acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1[3], acc[1][mt], 0, 0, 0);
             }
         }
+    }
+}
+
+// Epilogue of the common ops -- every output tile live, all 32 points of the wavefront valid, the store (if any) covering whole
+// aligned float4 rows and not accumulating, the result replacing the state: per tile 4 activations + one 16-byte store, the
+// only branches wave-uniform (scalar) ones on the op's kind.  (The generic epilogue below decides validity, vector or scalar
+// store, accumulation and the channel bound per tile and per channel at run time; the compiler turned that into ~20 branches
+// and exec-mask sequences per tile, a quarter of the kernel's time with stores.)
+template <int HT>
+__device__ __forceinline__ void mlp_epilogue_plain(const f32x4 (&acc)[2][HT], f32x4 (&prev)[2][HT], const SrMlpOp& L, float slope,
+                                                   const uint32_t (&mbits)[2], int p0, int n, int k) {
+    const bool leaky = L.epilogue == SR_MLP_LEAKY, has_store = L.store != nullptr, has_signs = L.sign_store != nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float* dst = L.store + (size_t)(p0 + 16 * nt + n) * L.store_row + 4 * k;
+        uint32_t signs = 0u;                                // bit 4 mt + i: channel 16 mt + 4 k + i of this point is > 0
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+            f32x4 r = acc[nt][mt];
+            if (leaky) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], slope * r[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] *= (mbits[nt] >> (4 * mt + i)) & 1u ? 1.0f : slope;
+            }
+            if (has_signs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) signs |= (r[i] > 0.f ? 1u : 0u) << (4 * mt + i);
+            }
+            if (has_store) *reinterpret_cast<float4*>(dst + 16 * mt) = make_float4(r[0], r[1], r[2], r[3]);
+            prev[nt][mt] = r;
+        }
+        if (has_signs) L.sign_store[(size_t)(p0 + 16 * nt + n) * 4 + k] = signs;
     }
 }
 
@@ -160,6 +195,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
             }
         }
         // ---- epilogue: channel 16 mt + 4 k + i of point (nt, n) ----
+        const bool plain = full && p0 + 32 <= n_points && !L.keep_state &&
+                           (L.epilogue == SR_MLP_LEAKY || (L.epilogue == SR_MLP_MASK && L.mask_bits)) &&
+                           (!L.store || (store_vec && L.store_channels == 16 * HT && !L.store_accumulate));   // wave-uniform
+        if (plain) { mlp_epilogue_plain<HT>(acc, prev, L, slope, mbits, p0, n, k); continue; }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             uint32_t signs = 0u;                                // bit 4 mt + i: channel 16 mt + 4 k + i of this point is > 0
