@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [tiles_padded]
     __shared__ uint32_t s_off[kBlock + 1];
     __shared__ ushort4 s_rect[kBlock];
+    __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat (record words 0 and 1): the tile_reached test
     __shared__ uint32_t s_scan[8];
     for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
     const int sb0 = blockIdx.x * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
@@ -48,15 +49,18 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
         const int idx = sb * kBlock + threadIdx.x;
         uint32_t touched = 0;
         ushort4 rect = make_ushort4(0, 0, 0, 0);
-        if (idx < N) { touched = g.touched[idx]; rect = g.rect[idx]; }
+        float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = r0;
+        if (idx < N) { touched = g.touched[idx]; rect = g.rect[idx]; if (touched >= kCullMinTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; } }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // starts with a barrier: protects s_off reuse
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
+        s_r0[threadIdx.x] = r0;
+        s_r1[threadIdx.x] = r1;
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
-            atomicAdd(&s_hist[tile], 1u);  // LDS atomic
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
+            if (rect_tiles < kCullMinTiles || tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&s_hist[tile], 1u);  // LDS atomic
         });
     }
     __syncthreads();
@@ -205,6 +209,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     __shared__ uint32_t s_off[kBlock + 1];
     __shared__ ushort4 s_rect[kBlock];
     __shared__ uint32_t s_depth[kBlock];
+    __shared__ float4 s_r0[kBlock], s_r1[kBlock];
     __shared__ uint32_t s_scan[8];
     if (g.total[0] > b.capacity) return;  // binning buffer too small: the host re-runs stage 2 with a larger one
     int sb0 = blockIdx.x, sb1 = blockIdx.x + 1;
@@ -232,10 +237,12 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         uint32_t touched = 0;
         ushort4 rect = make_ushort4(0, 0, 0, 0);
         uint32_t dbits = 0;
+        float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = r0;
         if (idx < N) {
             touched = g.touched[idx];
             rect = g.rect[idx];
             dbits = g.depth_bits[idx];  // view depth > 0.2: float bits sort as integers
+            if (touched >= kCullMinTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; }
         }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // leading barrier protects LDS reuse
@@ -244,11 +251,14 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
         s_depth[threadIdx.x] = dbits;
+        s_r0[threadIdx.x] = r0;
+        s_r1[threadIdx.x] = r1;
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         const uint32_t first_splat = (uint32_t)sb * kBlock;
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst) {
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
             b.reached[base + local_inst] = 0;   // instance order: consecutive threads, consecutive bytes
+            if (rect_tiles >= kCullMinTiles && !tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) return;   // as in the count pass
             uint32_t slot;
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);

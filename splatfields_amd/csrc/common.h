@@ -309,10 +309,11 @@ __device__ __forceinline__ float edge_min(float a, float b2, float c, float inv_
     const float t = fminf(hi, fmaxf(lo, -0.5f * b2 * fixed * inv_c));
     return a * fixed * fixed + (b2 * fixed + c * t) * t;
 }
-__device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1, float sx, float sy) {
+// box: pixel centres [sx, sx + extent] x [sy, sy + extent]
+__device__ __forceinline__ bool box_overlap(const float4 r0, const float4 r1, float sx, float sy, float extent) {
     const float tau = r0.z;
     if (!(tau > 0.0f)) return false;
-    const float x0 = sx - r0.x, x1 = x0 + (kSub - 1), y0 = sy - r0.y, y1 = y0 + (kSub - 1);  // box relative to the centre
+    const float x0 = sx - r0.x, x1 = x0 + extent, y0 = sy - r0.y, y1 = y0 + extent;  // box relative to the centre
     const bool in_x = x0 <= 0.0f && x1 >= 0.0f, in_y = y0 <= 0.0f && y1 >= 0.0f;
     if (in_x && in_y) return true;
     float A, B, C;
@@ -324,6 +325,24 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
     fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y0, x0, x1));
     fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y1, x0, x1));
     return fmin_ <= tau * 1.002f + 0.03f;
+}
+__device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1, float sx, float sy) {
+    return box_overlap(r0, r1, sx, sy, (float)(kSub - 1));
+}
+// The same test for a whole 16x16 tile: the bucketing drops the (splat, tile) instances of a splat's tile rectangle whose tile
+// holds no pixel the splat can reach with alpha >= 1/255 (the corners of the rectangle around a slanted or faint ellipse).
+// Such an instance is blended by the published pipeline too, with every pixel failing the alpha test: it changes no output and
+// no gradient, only the list lengths every later stage works through.
+// Applied to splats whose rectangle has at least kCullMinTiles tiles: below that almost every tile is reached (the rectangle
+// is already the bounding box of the support), and the test -- plus 32 bytes of record per splat in the two passes that
+// apply it -- costs more than the few entries it removes (headline workload, test on every instance: +18 us for -15 us;
+// from 4 tiles on: step -0.5 %, dense scenes -3.5 %, their sort -27 %).
+#ifndef SR_CULL_MIN_TILES
+#define SR_CULL_MIN_TILES 4
+#endif
+constexpr uint32_t kCullMinTiles = SR_CULL_MIN_TILES;
+__device__ __forceinline__ bool tile_reached(const float4 r0, const float4 r1, uint32_t tile_x, uint32_t tile_y) {
+    return box_overlap(r0, r1, (float)(tile_x * kTile), (float)(tile_y * kTile), (float)(kTile - 1));
 }
 
 #endif  // __HIPCC__

@@ -10,7 +10,7 @@ namespace sr {
 
 #ifdef __HIPCC__
 // s_off: [kBlock+1] exclusive offsets, s_off[kBlock] = block total.  s_rect: [kBlock] tile rects.
-// f(local_splat, k_within_splat, tile_index, local_instance)
+// f(local_splat, k_within_splat, tile_index, local_instance, tile_x, tile_y, tiles in the splat's rect)
 template <typename F>
 __device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, const ushort4* s_rect, int gx, F&& f) {
     const uint32_t total = s_off[kBlock];
@@ -25,7 +25,7 @@ __device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, c
         const ushort4 r = s_rect[lo];
         const uint32_t w = (uint32_t)(r.z - r.x);
         const uint32_t ty = k / w, tx = k - ty * w;
-        f(lo, k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i);
+        f(lo, k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, w * (uint32_t)(r.w - r.y));
     }
 }
 #endif

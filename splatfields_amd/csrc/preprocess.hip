@@ -135,6 +135,7 @@ template <bool STAGE_SH, bool COUNT_ATOMIC>
 __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const SplatsK s, const Geom g, int* __restrict__ radii) {
     __shared__ uint32_t s_off[COUNT_ATOMIC ? kBlock + 1 : 1];
     __shared__ ushort4 s_rect[COUNT_ATOMIC ? kBlock : 1];
+    __shared__ float4 s_r0[COUNT_ATOMIC ? kBlock : 1], s_r1[COUNT_ATOMIC ? kBlock : 1];   // ellipses for the tile_reached test
     __shared__ uint32_t s_scan[8];
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
 
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     const float* pm = v.projmatrix;
     uint32_t touched = 0, depth_bits = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
+    float4 ell0 = make_float4(0.f, 0.f, -1.f, 0.f), ell1 = ell0;
 
     // issue this splat's own loads first, then the staged SH block: everything is in flight together
     float3 p = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
@@ -273,12 +275,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         if (rgb.z < 0.f) { flags |= kFlagClampB; rgb.z = 0.f; }
                     }
                     float4* rec = g.rec + 4 * (size_t)idx;
-                    rec[0] = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
+                    ell0 = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
+                    rec[0] = ell0;
                     depth_bits = __float_as_uint(pv.z);
                     // exponent factors (common.h, pair_alpha_unclamped): all well conditioned, c >= 0.3 by the dilation
                     const float inv_c = 1.0f / c;
-                    rec[1] = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
-                                         opac > 0.0f ? -__log2f(opac) : 0.0f);
+                    ell1 = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
+                                       opac > 0.0f ? -__log2f(opac) : 0.0f);
+                    rec[1] = ell1;
                     rec[2] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);  // the blend kernels read the depth with the colour: one 16-byte LDS read
                     // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
                     // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
@@ -303,10 +307,12 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         // (block-cooperative expansion keeps large splats from serialising a lane)
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
+        s_r0[threadIdx.x] = ell0;
+        s_r1[threadIdx.x] = ell1;
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int, uint32_t, uint32_t tile, uint32_t) {
-            atomicAdd(&g.tile_count[tile], 1u);
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
+            if (rect_tiles < kCullMinTiles || tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&g.tile_count[tile], 1u);
         });
     }
 }

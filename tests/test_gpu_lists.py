@@ -2,10 +2,11 @@
 per-tile lists (membership and order) and the instance accounting.
 
 The kernels emit a (splat, tile) instance only where the splat's alpha >= 1/255 support can reach the tile, inside
-upstream's 3-sigma tile rectangle.  So, per tile:
+upstream's 3-sigma tile rectangle (the rectangle is clipped to the support's bounding box, and
+for rectangles of >= 4 tiles each tile is tested against the ellipse itself).  So, per tile:
   * the HIP list is a subset of the oracle's 3-sigma list, in the same (depth, splat index) order;
   * every oracle entry the HIP list leaves out has alpha < 1/255 on every pixel of the tile (nothing blended is lost);
-  * sum of list lengths == instance count == what the facade reports."""
+  * sum of list lengths <= instance count == what the facade reports."""
 import ctypes as C
 
 import pytest
@@ -38,7 +39,7 @@ def hip_tile_lists(sp, st, dev):
     i32 = lambda buf, o, cnt: buf[o:o + 4 * cnt].view(torch.int32).cpu().to(torch.int64)
     tile_start = i32(geom, off[0], tiles + 1)
     total = i32(geom, off[2], 4)
-    sorted_id = i32(binning, off[1], int(total[0]))
+    sorted_id = i32(binning, off[1], int(tile_start[-1]))      # list entries <= instances (tile_reached, csrc/common.h)
     return tile_start, sorted_id, int(total[0]), int(rz.LAST_INSTANCES), radii.cpu()
 
 
@@ -46,7 +47,9 @@ def hip_tile_lists(sp, st, dev):
 def test_tile_lists_match_the_oracle(hip_device, n, w, h, scale):
     sp, cam, st, grads = make_scene(n, w, h, mean_scale=scale, view=4)
     tile_start, sorted_id, total, reported, radii = hip_tile_lists(sp, st, hip_device)
-    assert total == reported == int(tile_start[-1]) == sorted_id.numel()
+    # instances = tiles of every splat's rectangle (what the facade reports and sizes the per-instance buffers by); the lists hold
+    # the instances whose tile the splat can reach
+    assert total == reported >= int(tile_start[-1]) == sorted_id.numel()
     assert (tile_start[1:] >= tile_start[:-1]).all()
 
     d64 = {k: v.double() for k, v in sp.items()}
