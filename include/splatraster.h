@@ -313,14 +313,21 @@ size_t sr_mlp_weight_grad_workspace(int n_points, int n_jobs, const SrMlpGradJob
 int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Input matrix of a GeneralMLP (reference utils/time_utils.py:9-57 `get_embedder`, :178-181): row p of x0 [N, row] =
- * [ x (3) | sin(2^0 x) | cos(2^0 x) | ... | sin(2^(L-1) x) | cos(2^(L-1) x) | features (n_features) | zeros up to `row` ],
- * the layout sr_mlp_chain reads; `row` a multiple of 4 (the fused MLP pads to 32).  Backward: given dL/dx0,
- * d_xyz = g[0:3] + sum_j 2^j (cos(2^j x) g_sin_j - sin(2^j x) g_cos_j) and d_features = the feature columns of g
+ * [ x (3) | sin(2^0 x) | cos(2^0 x) | ... | sin(2^(L-1) x) | cos(2^(L-1) x) | features (n_features) | time encoding | zeros up to `row` ],
+ * the layout sr_mlp_chain reads; `row` a multiple of 4 (the fused MLP pads to 32).  `time` (may be NULL): one value per point,
+ * encoded as [ t | sin(2^0 t) | cos(2^0 t) | ... | sin(2^(TL-1) t) | cos(2^(TL-1) t) ], TL = time_multires -- the time embedding the
+ * reference appends to the features of every network (utils/time_utils.py:455-456); it receives no gradient.  Backward: given
+ * dL/dx0, d_xyz = g[0:3] + sum_j 2^j (cos(2^j x) g_sin_j - sin(2^j x) g_cos_j) and d_features = the feature columns of g
  * (either may be NULL). */
-int sr_mlp_input_forward(int n_points, int multires, int n_features, int row, const float* xyz, const float* features, float* x0,
-                         void* hip_stream);
+int sr_mlp_input_forward(int n_points, int multires, int n_features, int time_multires, int row, const float* xyz, const float* features,
+                         const float* time, float* x0, void* hip_stream);
 int sr_mlp_input_backward(int n_points, int multires, int n_features, int row, const float* xyz, const float* dL_dx0, float* dL_dxyz,
                           float* dL_dfeatures, void* hip_stream);
+/* Top of the backward of a GeneralMLP (the activation follows EVERY layer, the last one included: reference
+ * utils/time_utils.py:178-191): g[p][c] = dL_dy[p][c] * (y[p][c] > 0 ? 1 : negative_slope) for c < out_features, 0 for
+ * out_features <= c < row -- the padded matrix the backward chain's first op and the last layer's weight gradient read. */
+int sr_mlp_top_gradient(int n_points, int out_features, int row, const float* y, const float* dL_dy, float negative_slope, float* g,
+                        void* hip_stream);
 
 /* ResField weights of the current frame for all layers of one network in one launch (reference utils/resfields.py:185,229,
  * 294-300,378-405 in the configuration GeneralMLP builds -- compression 'vm', mode 'lookup', fuse 'add'):

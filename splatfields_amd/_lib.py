@@ -97,7 +97,8 @@ SYMBOLS = {
     "sr_mlp_weight_grad_workspace": (C.c_size_t, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob)]),
     "sr_mlp_weight_grad": (C.c_int, [C.c_int, C.c_int, C.POINTER(SrMlpGradJob), C.c_void_p, C.c_size_t, C.c_void_p]),
     "sr_mlp_chain": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SrMlpOp), C.c_float, C.c_void_p]),
-    "sr_mlp_input_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_mlp_input_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sr_mlp_top_gradient": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "sr_mlp_input_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_resfield_compose": (C.c_int, [C.c_int, C.POINTER(SrResFieldJob), C.c_void_p, C.c_void_p]),
     "sr_resfield_backward_workspace": (C.c_size_t, [C.c_int, C.POINTER(SrResFieldJob)]),

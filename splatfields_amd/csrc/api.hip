@@ -408,11 +408,20 @@ int sr_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, void*
     return check_hip(hipGetLastError(), "mlp_weight_grad");
 }
 
-int sr_mlp_input_forward(int n_points, int multires, int n_features, int row, const float* xyz, const float* features, float* x0,
-                         void* hip_stream) {
-    if (sr::launch_mlp_input_forward(n_points, multires, n_features, row, xyz, features, x0, static_cast<hipStream_t>(hip_stream)))
-        return fail("bad arguments to sr_mlp_input_forward (row a multiple of 4 and >= 3 + 6 multires + n_features, multires <= 16)");
+int sr_mlp_input_forward(int n_points, int multires, int n_features, int time_multires, int row, const float* xyz, const float* features,
+                         const float* time, float* x0, void* hip_stream) {
+    if (sr::launch_mlp_input_forward(n_points, multires, n_features, time_multires, row, xyz, features, time, x0, static_cast<hipStream_t>(hip_stream)))
+        return fail("bad arguments to sr_mlp_input_forward (row a multiple of 4 and >= 3 + 6 multires + n_features [+ 1 + 2 time_multires "
+                    "with a time], both multires <= 16)");
     return check_hip(hipGetLastError(), "mlp_input_forward");
+}
+
+int sr_mlp_top_gradient(int n_points, int out_features, int row, const float* y, const float* dL_dy, float negative_slope, float* g,
+                        void* hip_stream) {
+    if (!(negative_slope >= 0.0f && negative_slope < 1.0f)) return fail("sr_mlp_top_gradient: negative_slope must be in [0, 1)");
+    if (sr::launch_mlp_top_gradient(n_points, out_features, row, y, dL_dy, negative_slope, g, static_cast<hipStream_t>(hip_stream)))
+        return fail("bad arguments to sr_mlp_top_gradient (row a multiple of 4 and >= out_features)");
+    return check_hip(hipGetLastError(), "mlp_top_gradient");
 }
 
 int sr_mlp_input_backward(int n_points, int multires, int n_features, int row, const float* xyz, const float* dL_dx0, float* dL_dxyz,

@@ -59,7 +59,8 @@ int launch_mlp_weight_grad(int n_points, int n_jobs, const SrMlpGradJob* jobs, v
 int launch_mlp_pack(int n_jobs, const SrMlpPackJob* jobs, hipStream_t st);
 int launch_mlp_chain(int n_points, int hidden_tiles, int n_ops, const SrMlpOp* ops, float slope, hipStream_t st);
 
-int launch_mlp_input_forward(int N, int L, int F, int row, const float* xyz, const float* feat, float* x0, hipStream_t st);
+int launch_mlp_input_forward(int N, int L, int F, int TL, int row, const float* xyz, const float* feat, const float* time, float* x0, hipStream_t st);
+int launch_mlp_top_gradient(int N, int out, int row, const float* y, const float* dy, float slope, float* G, hipStream_t st);
 int launch_mlp_input_backward(int N, int L, int F, int row, const float* xyz, const float* g, float* d_xyz, float* d_feat, hipStream_t st);
 int launch_resfield_compose(int n_jobs, const SrResFieldJob* jobs, const long long* frame, hipStream_t st);
 size_t resfield_backward_workspace(int n_jobs, const SrResFieldJob* jobs);

@@ -615,14 +615,17 @@ int launch_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long l
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Network input of a GeneralMLP (reference utils/time_utils.py:9-57 `get_embedder` + :178-181): row p of the padded input
-// matrix = [ x (3) | sin(2^0 x) (3) | cos(2^0 x) (3) | ... | sin(2^(L-1) x) | cos(2^(L-1) x) | features (F) | 0 ... ].
+// matrix = [ x (3) | sin(2^0 x) (3) | cos(2^0 x) (3) | ... | sin(2^(L-1) x) | cos(2^(L-1) x) | features (F) | time encoding | 0 ... ],
+// time encoding = [ t | sin(2^0 t) | cos(2^0 t) | ... | sin(2^(TL-1) t) | cos(2^(TL-1) t) ] when a time per point is given
+// (reference utils/time_utils.py:455-456: the time embedding is the tail of the feature vector every network receives).
 // One launch instead of the reference's 2 L multiplies, 2 L sin / cos, two concatenations and the padding copy (and as many
 // again backward): ~60 small kernels per network and step.
 // ------------------------------------------------------------------------------------------------------------------------
 namespace sr {
 
-__global__ void __launch_bounds__(kBlock) k_mlp_input_forward(int N, int L, int F, int row, const float* __restrict__ xyz,
-                                                              const float* __restrict__ feat, float* __restrict__ x0) {
+__global__ void __launch_bounds__(kBlock) k_mlp_input_forward(int N, int L, int F, int TL, int row, const float* __restrict__ xyz,
+                                                              const float* __restrict__ feat, const float* __restrict__ time,
+                                                              float* __restrict__ x0) {
     const int q = row >> 2;
     const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)N * q) return;
@@ -639,6 +642,12 @@ __global__ void __launch_bounds__(kBlock) k_mlp_input_forward(int N, int L, int 
             const float a = x[r < 3 ? r : r - 3] * (float)(1 << j);
             o = r < 3 ? sinf(a) : cosf(a);
         } else if (c < 3 + 6 * L + F) o = feat[(size_t)p * F + (c - 3 - 6 * L)];
+        else if (time && c < 3 + 6 * L + F + 1 + 2 * TL) {
+            const int m = c - (3 + 6 * L + F);
+            const float tv = time[p];
+            if (m == 0) o = tv;
+            else { const float a = tv * (float)(1 << ((m - 1) >> 1)); o = ((m - 1) & 1) ? cosf(a) : sinf(a); }
+        }
         v[i] = o;
     }
     reinterpret_cast<float4*>(x0)[t] = make_float4(v[0], v[1], v[2], v[3]);
@@ -672,11 +681,38 @@ __global__ void __launch_bounds__(kBlock) k_mlp_input_backward(int N, int L, int
     }
 }
 
-int launch_mlp_input_forward(int N, int L, int F, int row, const float* xyz, const float* feat, float* x0, hipStream_t st) {
-    if (N < 0 || L < 0 || L > 16 || F < 0 || (row & 3) || row < 3 + 6 * L + F || (F > 0 && !feat) || !xyz || !x0) return 1;
+int launch_mlp_input_forward(int N, int L, int F, int TL, int row, const float* xyz, const float* feat, const float* time, float* x0,
+                             hipStream_t st) {
+    if (N < 0 || L < 0 || L > 16 || F < 0 || TL < 0 || TL > 16 || (row & 3) || row < 3 + 6 * L + F + (time ? 1 + 2 * TL : 0) ||
+        (F > 0 && !feat) || !xyz || !x0) return 1;
     if (N == 0) return 0;
     const long long threads = (long long)N * (row >> 2);
-    hipLaunchKernelGGL(k_mlp_input_forward, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, L, F, row, xyz, feat, x0);
+    hipLaunchKernelGGL(k_mlp_input_forward, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, L, F, TL, row, xyz, feat, time, x0);
+    return 0;
+}
+
+// Top of a network's backward: G[p][c] = dL/dy[p][c] * leaky'(y[p][c]) for c < out, 0 up to the padded row (the memory input of
+// the backward chain's first op and the dZ operand of the last layer's weight gradient).
+__global__ void __launch_bounds__(kBlock) k_mlp_top_gradient(int N, int out, int row, const float* __restrict__ y, const float* __restrict__ dy,
+                                                             float slope, float* __restrict__ G) {
+    const int q = row >> 2;
+    const long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)N * q) return;
+    const int p = (int)(t / q), c0 = 4 * (int)(t % q);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i;
+        v[i] = c < out ? dy[(size_t)p * out + c] * (y[(size_t)p * out + c] > 0.f ? 1.0f : slope) : 0.0f;
+    }
+    reinterpret_cast<float4*>(G)[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+int launch_mlp_top_gradient(int N, int out, int row, const float* y, const float* dy, float slope, float* G, hipStream_t st) {
+    if (N < 0 || out < 1 || (row & 3) || row < out || !y || !dy || !G) return 1;
+    if (N == 0) return 0;
+    const long long threads = (long long)N * (row >> 2);
+    hipLaunchKernelGGL(k_mlp_top_gradient, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, N, out, row, y, dy, slope, G);
     return 0;
 }
 

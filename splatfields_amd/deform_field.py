@@ -156,22 +156,31 @@ class SplatFields(nn.Module):
         if self.n_frames > 0:
             time_step = t.view(-1)[0]
             frame_id = self._time2frame_id(time_step).long()
-        feat = self.extract_features(xyz_in, t)
+        # features of every network: [refined tri-plane features | time embedding] (extract_features).  With one float32 time per
+        # point that takes no gradient, the time embedding is written by the networks' input kernel instead of ~15 small kernels
+        # and a concatenation per step.
+        fuse_time = self.n_frames > 0 and torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and not t.requires_grad and \
+            t.numel() == xyz_in.shape[0] and not self.geo_model_disable_pts
+        if fuse_time:
+            feat = self.mlp_refine_feat(self.encoder(xyz_in[None]).squeeze(0)) if self.feat_dim > 0 else None
+            tk = dict(time=t.reshape(-1), time_multires=self.time_multires)
+        else:
+            feat, tk = self.extract_features(xyz_in, t), {}
         if self.deform_weight > 0:
-            xyz_can = xyz_in + self.deform_weight * self.mlp_deform(xyz_in, feat, frame_id=frame_id)
+            xyz_can = xyz_in + self.deform_weight * self.mlp_deform(xyz_in, feat, frame_id=frame_id, **tk)
         else:
             xyz_can = xyz_in
         geo_xyz, geo_feat = (feat, None) if self.geo_model_disable_pts else (xyz_can, feat)
-        out["scales"] = self.mlp_scale(geo_xyz, geo_feat, frame_id=frame_id)
-        out["opacity"] = self.mlp_opacity(geo_xyz, geo_feat, frame_id=frame_id)
-        out["rotations"] = self.mlp_rotation(geo_xyz, geo_feat, frame_id=frame_id)
-        rgb = self.mlp_rgb(xyz_can, feat, frame_id=frame_id)
+        out["scales"] = self.mlp_scale(geo_xyz, geo_feat, frame_id=frame_id, **tk)
+        out["opacity"] = self.mlp_opacity(geo_xyz, geo_feat, frame_id=frame_id, **tk)
+        out["rotations"] = self.mlp_rotation(geo_xyz, geo_feat, frame_id=frame_id, **tk)
+        rgb = self.mlp_rgb(xyz_can, feat, frame_id=frame_id, **tk)
         if self.use_view_dep_rgb:
             out["rgb_fnc"] = lambda viewdir: self.mlp_rgb_viewdep(torch.cat([rgb, viewdir], dim=-1))
         else:
             out["rgb"] = rgb
         if self.n_frames > 0:
-            flow_feat = self.mlp_flow(xyz_can, feat, frame_id=frame_id)
+            flow_feat = self.mlp_flow(xyz_can, feat, frame_id=frame_id, **tk)
             flow, means3D = self.mlp_flow_head(hidden=flow_feat, pts=xyz_can, time_step=time_step, frame_id=frame_id)
         else:
             flow, means3D = None, xyz_can

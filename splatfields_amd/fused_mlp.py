@@ -180,6 +180,7 @@ def _backward_plan(shape: _Shape, need_input: bool, bits: bool) -> _Plan:
     if key not in shape.plans:
         H, L = shape.hidden, shape.n_layers
         b = _Plan()
+        wrote_input = False        # dL/dx0 is not cleared beforehand: the first layer that feeds it (the topmost) stores, incl. zero padding
         for j in range(L - 1, -1, -1):
             ld = shape.layer_dims[j][1]
             top = j == L - 1
@@ -189,12 +190,14 @@ def _backward_plan(shape: _Shape, need_input: bool, bits: bool) -> _Plan:
                 dict(n_mem=0, mem_pad=0, n_reg=H, reg_width=H, reg_col0=0)
             src = dict(src=("G", 0, 0), src_row=shape.out_pad) if top else {}
             if need_input and n_mem_w:
-                for g0, cnt in shape.input_groups:                      # dL/dx0 += W_j[:, input block]^T dZ_j, <= ht tiles at a time
+                for g0, cnt in shape.input_groups:                      # dL/dx0 (+)= W_j[:, input block]^T dZ_j, <= ht tiles at a time
                     rows = min(16 * cnt, shape.d_in - 16 * g0)
                     job = dict(w=("W", j, 0), ld=ld, transposed=1, row0=16 * g0, n_rows=rows, out_tiles=cnt, **cols)
+                    # packed rows beyond `rows` are zero: storing all 16 cnt channels also writes the padding columns' zeros
                     op = dict(epilogue=_lib.MLP_NONE, keep_state=1, store=("dx0", 0, 4 * 16 * g0), store_row=shape.mem_pad,
-                              store_channels=rows, store_accumulate=1, **src)
+                              store_channels=rows if wrote_input else 16 * cnt, store_accumulate=1 if wrote_input else 0, **src)
                     b.add(job, op, with_bias=False)
+                wrote_input = True
             if j > 0:                                                   # dZ_{j-1} = (W_j[:, hidden block]^T dZ_j) * act'(h_{j-1})
                 job = dict(w=("W", j, 0), ld=ld, transposed=1, row0=n_mem_w, n_rows=H, out_tiles=shape.ht, **cols)
                 mask = dict(mask_bits=("signs", j - 1, 0)) if bits else dict(mask=("acts", j - 1, 0), mask_row=H)
@@ -204,15 +207,23 @@ def _backward_plan(shape: _Shape, need_input: bool, bits: bool) -> _Plan:
     return shape.plans[key]
 
 
+def _top_gradient(lib, shape: _Shape, y, dY, slope: float, G):
+    """G[:, :out] = dY * leaky'(y), zero padding behind: one launch (sr_mlp_top_gradient)"""
+    dev = y.device
+    with torch.cuda.device(dev):
+        _lib.check(lib.sr_mlp_top_gradient(y.shape[0], shape.out_features, shape.out_pad, C.c_void_p(y.data_ptr()), C.c_void_p(dY.data_ptr()),
+                                           slope, C.c_void_p(G.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
 def _backward(shape: _Shape, x0, acts, y, dY, weights, slope: float, need_input: bool, signs=None):
     """-> (dL/dx0 [N, mem_pad] or None, G [N, out_pad] = dZ of the last layer (zero-padded), dz [L-1, N, hidden] = dZ of the others).
     leaky'(.) of the hidden layers is read off `signs` (16 bytes per point and layer) when given, else off `acts` (4 * hidden)."""
     lib = _lib.load()
     dev, n, H, L = x0.device, x0.shape[0], shape.hidden, shape.n_layers
-    gz = dY * torch.where(y > 0, 1.0, slope)
-    G = F.pad(gz, (0, shape.out_pad - shape.out_features)).contiguous()
+    G = torch.empty(n, shape.out_pad, dtype=torch.float32, device=dev)
     dz = torch.empty(L - 1, n, H, dtype=torch.float32, device=dev)
-    dx0 = torch.zeros(n, shape.mem_pad, dtype=torch.float32, device=dev) if need_input else None
+    dx0 = torch.empty(n, shape.mem_pad, dtype=torch.float32, device=dev) if need_input else None   # the chain's first input op stores
+    _top_gradient(lib, shape, y, dY, slope, G)
     ptrs = {"W": [w.data_ptr() for w in weights], "G": (G.data_ptr(),), "dx0": (dx0.data_ptr() if need_input else 0,),
             "acts": [acts.data_ptr() + 4 * j * n * H for j in range(L - 1)], "dz": [dz.data_ptr() + 4 * j * n * H for j in range(L - 1)],
             "signs": [signs.data_ptr() + 16 * j * n for j in range(L - 1)] if signs is not None else ()}
@@ -324,7 +335,7 @@ class _FusedMLPPointsFn(torch.autograd.Function):
     and step for the encoding, the concatenations, the padding and their backward."""
 
     @staticmethod
-    def forward(ctx, xyz, feat, shape: _Shape, slope: float, multires: int, grad_enabled: bool, *params):
+    def forward(ctx, xyz, feat, time, shape: _Shape, slope: float, multires: int, time_multires: int, grad_enabled: bool, *params):
         lib = _lib.load()
         L = shape.n_layers
         weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
@@ -332,11 +343,13 @@ class _FusedMLPPointsFn(torch.autograd.Function):
         dev, n = xyz.device, xyz.shape[0]
         x32 = xyz.detach().to(torch.float32).contiguous()
         f32 = feat.detach().to(torch.float32).contiguous() if feat is not None else None
+        t32 = time.detach().to(torch.float32).reshape(-1).contiguous() if time is not None else None
         n_feat = 0 if f32 is None else f32.shape[1]
         x0 = torch.empty(n, shape.mem_pad, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.sr_mlp_input_forward(n, multires, n_feat, shape.mem_pad, C.c_void_p(x32.data_ptr()),
-                                                C.c_void_p(f32.data_ptr()) if f32 is not None else None, C.c_void_p(x0.data_ptr()),
+            _lib.check(lib.sr_mlp_input_forward(n, multires, n_feat, time_multires, shape.mem_pad, C.c_void_p(x32.data_ptr()),
+                                                C.c_void_p(f32.data_ptr()) if f32 is not None else None,
+                                                C.c_void_p(t32.data_ptr()) if t32 is not None else None, C.c_void_p(x0.data_ptr()),
                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         need = grad_enabled and any(ctx.needs_input_grad)
         y, acts, signs = _forward(shape, x0, weights, biases, slope, save=need)
@@ -363,33 +376,39 @@ class _FusedMLPPointsFn(torch.autograd.Function):
                                                      C.c_void_p(d_feat.data_ptr()) if need_feat else None,
                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         dWs, dbs = [None] * L, [None] * L
-        if any(ctx.needs_input_grad[6:]):
+        if any(ctx.needs_input_grad[8:]):
             dWs, dbs = _weight_grads(shape, x0, acts, G, dz, weights)
-            dWs = [g if ctx.needs_input_grad[6 + j] else None for j, g in enumerate(dWs)]
-            dbs = [g if ctx.needs_input_grad[6 + L + j] else None for j, g in enumerate(dbs)]
-        return (d_xyz, d_feat, None, None, None, None, *dWs, *dbs)
+            dWs = [g if ctx.needs_input_grad[8 + j] else None for j, g in enumerate(dWs)]
+            dbs = [g if ctx.needs_input_grad[8 + L + j] else None for j, g in enumerate(dbs)]
+        return (d_xyz, d_feat, None, None, None, None, None, None, *dWs, *dbs)
 
 
 def fused_general_mlp_points(xyz: torch.Tensor, feat: Optional[torch.Tensor], multires: int, weights: Sequence[torch.Tensor],
                              biases: Sequence[torch.Tensor], skips: Sequence[int] = (), negative_slope: float = 0.01,
-                             _shape: Optional[_Shape] = None) -> torch.Tensor:
-    """`fused_general_mlp(cat([positional_encoding(xyz, multires), feat]), ...)` with the input matrix built on the device in
-    one kernel: xyz [N, 3], feat [N, F] or None, float32 on a HIP device."""
+                             _shape: Optional[_Shape] = None, time: Optional[torch.Tensor] = None, time_multires: int = 0) -> torch.Tensor:
+    """`fused_general_mlp(cat([positional_encoding(xyz, multires), feat, positional_encoding(time, time_multires)]), ...)` with the
+    input matrix built on the device in one kernel: xyz [N, 3], feat [N, F] or None, time [N] / [N, 1] or None (one time per point,
+    no gradient), float32 on a HIP device."""
     _lib.load()
     if not xyz.is_cuda:
         raise RuntimeError("fused_general_mlp_points has no CPU path: tensors must be on a HIP ('cuda') device")
     n_feat = 0 if feat is None else feat.shape[1]
-    d_in = 3 * (1 + 2 * max(multires, 0)) + n_feat
+    time_multires = int(max(time_multires, 0))
+    n_time = 0 if time is None else 1 + 2 * time_multires
+    d_in = 3 * (1 + 2 * max(multires, 0)) + n_feat + n_time
     shape = _shape or _Shape(weights, d_in, skips)
     if xyz.dim() != 2 or xyz.shape[1] != 3 or shape.d_in != d_in or (feat is not None and (feat.dim() != 2 or feat.shape[0] != xyz.shape[0])):
-        raise ValueError(f"xyz must be [N, 3] and feat [N, {shape.d_in - 3 * (1 + 2 * max(multires, 0))}]")
+        raise ValueError(f"xyz must be [N, 3] and feat [N, {shape.d_in - 3 * (1 + 2 * max(multires, 0)) - n_time}]")
     if xyz.dtype != torch.float32 or (feat is not None and (feat.dtype != torch.float32 or feat.device != xyz.device)):
         raise ValueError("xyz and feat must be float32 tensors on the same device")
+    if time is not None and (time.numel() != xyz.shape[0] or time.dtype != torch.float32 or time.device != xyz.device or time.requires_grad):
+        raise ValueError("time must hold one float32 value per point on the same device and take no gradient")
     if not (0.0 <= negative_slope < 1.0) or len(biases) != shape.n_layers or len(weights) != shape.n_layers:
         raise ValueError("negative_slope must be in [0, 1) and there must be one weight and one bias per layer")
     if xyz.shape[0] == 0:
         return xyz.new_zeros(0, shape.out_features) + 0.0 * (xyz.sum() + sum(w.sum() for w in weights) + sum(b.sum() for b in biases))
-    return _FusedMLPPointsFn.apply(xyz, feat, shape, float(negative_slope), int(max(multires, 0)), torch.is_grad_enabled(), *weights, *biases)
+    return _FusedMLPPointsFn.apply(xyz, feat, time, shape, float(negative_slope), int(max(multires, 0)), time_multires,
+                                   torch.is_grad_enabled(), *weights, *biases)
 
 
 def fused_general_mlp(h_in: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], skips: Sequence[int] = (),

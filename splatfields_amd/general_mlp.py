@@ -197,17 +197,21 @@ class GeneralMLP(nn.Module):
             self._shape = _Shape([l.weight for l in self.net], self.d_in, self.skips)
         return self._shape
 
-    def forward(self, xyz: torch.Tensor, xyz_feat: Optional[torch.Tensor] = None, frame_id=None) -> torch.Tensor:
+    def forward(self, xyz: torch.Tensor, xyz_feat: Optional[torch.Tensor] = None, frame_id=None, time: Optional[torch.Tensor] = None,
+                time_multires: int = 0) -> torch.Tensor:
+        """`time` (optional, one value per point, no gradient): its positional encoding is appended behind `xyz_feat` -- the tail
+        of the feature vector the reference passes in (utils/time_utils.py:455-456) -- inside the input kernel."""
         weights = compose_resfield_weights(list(self.net), frame_id)
         biases = [layer.bias for layer in self.net]
         if xyz.is_cuda and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.dtype == torch.float32 and \
                 (xyz_feat is None or (xyz_feat.dtype == torch.float32 and xyz_feat.dim() == 2)):
-            # the usual case: positions + features -> the padded input matrix in one kernel
+            # the usual case: positions + features (+ time) -> the padded input matrix in one kernel
             h = fused_general_mlp_points(xyz, xyz_feat, self.multires, weights, biases, skips=self.skips, negative_slope=self.slope,
-                                         _shape=self._static_shape())
+                                         _shape=self._static_shape(), time=time, time_multires=time_multires)
             return self.out_act(h)
         h_in = positional_encoding(xyz, self.multires)
-        if xyz_feat is not None:
-            h_in = torch.cat([h_in, xyz_feat], dim=-1)
+        parts = [h_in] + ([xyz_feat] if xyz_feat is not None else []) + \
+            ([positional_encoding(time.reshape(-1, 1), time_multires)] if time is not None else [])
+        h_in = torch.cat(parts, dim=-1) if len(parts) > 1 else h_in
         h = fused_general_mlp(h_in, weights, biases, skips=self.skips, negative_slope=self.slope, _shape=self._static_shape())
         return self.out_act(h)

@@ -106,6 +106,9 @@ def test_op_lists_compute_the_network_and_its_gradients(monkeypatch, d_in, H, nh
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: _Stream())
     monkeypatch.setattr(fm._Plan, "run", interpret)
+    # sr_mlp_top_gradient (include/splatraster.h): dY * leaky'(y), zero-padded to the row the backward chain reads
+    monkeypatch.setattr(fm, "_top_gradient", lambda lib, shape, y, dY, slope, G: G.copy_(
+        F.pad(dY * torch.where(y > 0, 1.0, slope), (0, shape.out_pad - shape.out_features))))
     g = torch.Generator().manual_seed(1)
     L = nh + 2
     dims_in = [d_in] + [H + (d_in if (j - 1) in skips else 0) for j in range(1, L)]

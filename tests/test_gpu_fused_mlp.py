@@ -346,3 +346,37 @@ def test_sign_bits_carry_the_activation_derivative(hip_device, d_in, hidden, n_h
     a = fm._backward(shape, x0, acts, y, dY, weights, slope, True, signs)
     b = fm._backward(shape, x0, acts, y, dY, weights, slope, True)
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_time_embedding_inside_the_input_kernel(hip_device):
+    """`fused_general_mlp_points(..., time=t, time_multires=3)` == the same network fed `cat([features, positional_encoding(t, 3)])`
+    (what the reference passes: utils/time_utils.py:455-456), output and every gradient; and sr_mlp_top_gradient / the un-cleared
+    dL/dx0 leave the padding columns zero."""
+    from splatfields_amd import fused_mlp as fm
+    from splatfields_amd.general_mlp import positional_encoding
+    dev = hip_device
+    n, F_, L, TL = 5000, 48, 6, 3
+    d_in = 3 * (1 + 2 * L) + F_ + 1 + 2 * TL
+    weights, biases = make_net(d_in, 128, 6, [3], 3, dev, 3)
+    for t_ in weights + biases:
+        t_.requires_grad_(True)
+    g = torch.Generator().manual_seed(9)
+    xyz = torch.randn(n, 3, generator=g).to(dev).requires_grad_(True)
+    feat = torch.randn(n, F_, generator=g).to(dev).requires_grad_(True)
+    t = torch.rand(n, 1, generator=g).to(dev)
+    dY = torch.randn(n, 3, generator=g).to(dev)
+    leaves = [xyz, feat] + weights + biases
+    a = fm.fused_general_mlp_points(xyz, feat, L, weights, biases, skips=[3], time=t, time_multires=TL)
+    ga = torch.autograd.grad(a, leaves, dY)
+    b = fm.fused_general_mlp_points(xyz, torch.cat([feat, positional_encoding(t, TL)], dim=-1), L, weights, biases, skips=[3])
+    gb = torch.autograd.grad(b, leaves, dY)
+    assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+    for u, v in zip(ga, gb):
+        assert (u - v).abs().max().item() <= 1e-5 * v.abs().max().item()
+    shape = fm._Shape(weights, d_in, [3])
+    x0 = F.pad(torch.randn(n, d_in, generator=g), (0, shape.mem_pad - d_in)).to(dev).contiguous()
+    wd, bd = [w.detach() for w in weights], [b_.detach() for b_ in biases]
+    y, acts, signs = fm._forward(shape, x0, wd, bd, 0.01, True)
+    dx0, G, dz = fm._backward(shape, x0, acts, y, dY, wd, 0.01, True, signs)
+    assert (dx0[:, d_in:] == 0).all() and (G[:, 3:] == 0).all()
+    assert torch.equal(G[:, :3], dY * torch.where(y > 0, 1.0, 0.01))
