@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat (record words 0 and 1): the tile_reached test
     __shared__ uint32_t s_scan[8];
     for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
-    const int sb0 = blockIdx.x * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+    const int base_chunk = (int)blockIdx.x / ch.slices, slice = (int)blockIdx.x % ch.slices;
+    const int sb0 = base_chunk * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
     for (int sb = sb0; sb < sb1; ++sb) {
         const int idx = sb * kBlock + threadIdx.x;
         uint32_t touched = 0;
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
         __syncthreads();
         for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
             if (rect_tiles < kCullMinTiles || tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&s_hist[tile], 1u);  // LDS atomic
-        });
+        }, (uint32_t)slice, (uint32_t)ch.slices);
     }
     __syncthreads();
     uint32_t* row = g.cnt + (size_t)blockIdx.x * ch.tiles_padded;
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     __shared__ uint32_t s_scan[8];
     if (g.total[0] > b.capacity) return;  // binning buffer too small: the host re-runs stage 2 with a larger one
     int sb0 = blockIdx.x, sb1 = blockIdx.x + 1;
+    uint32_t slice = 0, slices = 1;
     if constexpr (MATRIX) {
         // Which chunk this workgroup scatters.  Inside a tile's segment of `ent` the chunks' pieces (~1 entry each at 1 M
         // splats) follow each other in chunk order, and workgroup b runs on XCD b % 8 with its own L2: dealt round-robin,
@@ -226,7 +228,8 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
 #else
         const int chunk = (int)blockIdx.x;
 #endif
-        sb0 = chunk * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+        slice = (uint32_t)(chunk % ch.slices); slices = (uint32_t)ch.slices;
+        sb0 = (chunk / ch.slices) * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
         const uint32_t* row = g.cnt + (size_t)chunk * ch.tiles_padded;
         const uint32_t* sbase = g.segbase + (size_t)(chunk / kSegRows) * ch.tiles_padded;
         const int n_tiles = v.gx * v.gy;
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
             if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
             else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
             b.ent[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(first_splat + (uint32_t)e);
-        });
+        }, slice, slices);
     }
 }
 

@@ -73,13 +73,22 @@ constexpr int kMaxChunks = SR_MAX_CHUNKS;        // chunk = consecutive 256-spla
 constexpr int kSegRows = SR_SEG_ROWS;   // chunks per column-scan segment
 constexpr int kMaxMatrixTiles = 16384;  // LDS histogram of 64 KiB; larger images use the global-atomic fallback
 
-struct Chunking { int n_sub, chunks, sub_per_chunk, segments, tiles_padded; };
+// A chunk = `sub_per_chunk` consecutive sub-batches, or -- when there are fewer than kMaxChunks / 2 sub-batches -- one of
+// `slices` equal parts of the instance range of ONE sub-batch (chunk = sub-batch * slices + slice).  Small scenes with large
+// footprints (100 k splats x 70 tiles) otherwise leave the two instance passes with N / 256 workgroups, each walking 17 k
+// instances alone: 1.5 wavefronts per SIMD, 24 % of the VALU issue rate.
+struct Chunking { int n_sub, chunks, sub_per_chunk, slices, segments, tiles_padded; };
 inline Chunking make_chunking(int N, int tiles) {
     Chunking c;
     c.n_sub = (N + 255) / 256; if (c.n_sub < 1) c.n_sub = 1;
     const int b = c.n_sub < kMaxChunks ? c.n_sub : kMaxChunks;
     c.sub_per_chunk = (c.n_sub + b - 1) / b;
     c.chunks = (c.n_sub + c.sub_per_chunk - 1) / c.sub_per_chunk;
+    c.slices = 1;
+#ifndef SR_NO_CHUNK_SLICES
+    if (c.sub_per_chunk == 1) { c.slices = kMaxChunks / c.chunks; if (c.slices > 8) c.slices = 8; if (c.slices < 1) c.slices = 1; }
+#endif
+    c.chunks *= c.slices;
     c.segments = (c.chunks + kSegRows - 1) / kSegRows;
     c.tiles_padded = (tiles + 63) / 64 * 64;
     return c;

@@ -10,22 +10,41 @@ namespace sr {
 
 #ifdef __HIPCC__
 // s_off: [kBlock+1] exclusive offsets, s_off[kBlock] = block total.  s_rect: [kBlock] tile rects.
+// slice / slices: only the slice-th of `slices` equal parts of the instance list is walked.
 // f(local_splat, k_within_splat, tile_index, local_instance, tile_x, tile_y, tiles in the splat's rect)
 template <typename F>
-__device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, const ushort4* s_rect, int gx, F&& f) {
-    const uint32_t total = s_off[kBlock];
-    for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
-        int lo = 0, hi = kBlock;  // invariant: s_off[lo] <= i < s_off[hi]
+__device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, const ushort4* s_rect, int gx, F&& f, uint32_t slice = 0, uint32_t slices = 1) {
+    const uint32_t all = s_off[kBlock];
+    // this workgroup's share of the sub-batch's instances (Chunking::slices): [first, total)
+    const uint32_t per = (all + slices - 1u) / slices, first = min(all, slice * per), total = min(all, first + per);
+    // SR_EXPAND_ILP instances per thread and round: their binary searches (8 dependent LDS reads each) are independent chains
+    // the compiler interleaves.  A workgroup walks its instances alone (N / 256 workgroups: 1.5 wavefronts per SIMD at 100 k
+    // splats), so nothing else hides that latency: k_count_tiles ran at 24 % of the VALU issue rate in the dense regimes.
+#ifndef SR_EXPAND_ILP
+#define SR_EXPAND_ILP 4
+#endif
+    for (uint32_t i0 = first + threadIdx.x; i0 < total; i0 += SR_EXPAND_ILP * kBlock) {
+        int lo[SR_EXPAND_ILP], hi[SR_EXPAND_ILP];  // invariant: s_off[lo] <= i < s_off[hi]
+#pragma unroll
+        for (int u = 0; u < SR_EXPAND_ILP; ++u) { lo[u] = 0; hi[u] = kBlock; }
 #pragma unroll
         for (int step = 0; step < 8; ++step) {
-            const int mid = (lo + hi) >> 1;
-            if (s_off[mid] <= i) lo = mid; else hi = mid;
+#pragma unroll
+            for (int u = 0; u < SR_EXPAND_ILP; ++u) {
+                const int mid = (lo[u] + hi[u]) >> 1;
+                if (s_off[mid] <= min(i0 + (uint32_t)u * kBlock, total - 1u)) lo[u] = mid; else hi[u] = mid;
+            }
         }
-        const uint32_t k = i - s_off[lo];
-        const ushort4 r = s_rect[lo];
-        const uint32_t w = (uint32_t)(r.z - r.x);
-        const uint32_t ty = k / w, tx = k - ty * w;
-        f(lo, k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, w * (uint32_t)(r.w - r.y));
+#pragma unroll
+        for (int u = 0; u < SR_EXPAND_ILP; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * kBlock;
+            if (i >= total) break;
+            const uint32_t k = i - s_off[lo[u]];
+            const ushort4 r = s_rect[lo[u]];
+            const uint32_t w = (uint32_t)(r.z - r.x);
+            const uint32_t ty = k / w, tx = k - ty * w;
+            f(lo[u], k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, w * (uint32_t)(r.w - r.y));
+        }
     }
 }
 #endif
