@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];  // [tiles_padded]
     __shared__ uint32_t s_off[kBlock + 1];
     __shared__ ushort4 s_rect[kBlock];
-    __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat (record words 0 and 1): the tile_reached test
+    __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat, prepared for the tile_reached test
     __shared__ uint32_t s_scan[8];
     for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
     const int base_chunk = (int)blockIdx.x / ch.slices, slice = (int)blockIdx.x % ch.slices;
@@ -56,8 +56,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
         const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // starts with a barrier: protects s_off reuse
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
-        s_r0[threadIdx.x] = r0;
-        s_r1[threadIdx.x] = r1;
+        tile_test_prepare(r0, r1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
@@ -254,8 +253,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
         s_depth[threadIdx.x] = dbits;
-        s_r0[threadIdx.x] = r0;
-        s_r1[threadIdx.x] = r1;
+        tile_test_prepare(r0, r1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         const uint32_t first_splat = (uint32_t)sb * kBlock;

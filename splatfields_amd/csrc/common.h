@@ -350,8 +350,26 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
 #define SR_CULL_MIN_TILES 4
 #endif
 constexpr uint32_t kCullMinTiles = SR_CULL_MIN_TILES;
-__device__ __forceinline__ bool tile_reached(const float4 r0, const float4 r1, uint32_t tile_x, uint32_t tile_y) {
-    return box_overlap(r0, r1, (float)(tile_x * kTile), (float)(tile_y * kTile), (float)(kTile - 1));
+// The per-splat half of the test is done once (tile_test_prepare, by the thread that stages the splat of a sub-batch): e0 =
+// (centre x, centre y, threshold, A), e1 = (2 B, C, 1 / A, 1 / C) of the quadratic form; tile_reached then costs the four
+// edge minima only.  A splat that can never be seen has threshold < 0.
+__device__ __forceinline__ void tile_test_prepare(const float4 r0, const float4 r1, float4& e0, float4& e1) {
+    float A, B, C;
+    conic_from_factors(r1, A, B, C);
+    e0 = make_float4(r0.x, r0.y, r0.z > 0.0f ? r0.z * 1.002f + 0.03f : -1.0f, A);
+    e1 = make_float4(2.0f * B, C, __builtin_amdgcn_rcpf(A), __builtin_amdgcn_rcpf(C));
+}
+__device__ __forceinline__ bool tile_reached(const float4 e0, const float4 e1, uint32_t tile_x, uint32_t tile_y) {
+    if (!(e0.z > 0.0f)) return false;
+    const float x0 = (float)(tile_x * kTile) - e0.x, x1 = x0 + (float)(kTile - 1);  // the tile's pixel-centre box relative to the centre
+    const float y0 = (float)(tile_y * kTile) - e0.y, y1 = y0 + (float)(kTile - 1);
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return true;
+    const float A = e0.w, B2 = e1.x, C = e1.y, inv_a = e1.z, inv_c = e1.w;
+    float fmin_ = edge_min(A, B2, C, inv_c, x0, y0, y1);
+    fmin_ = fminf(fmin_, edge_min(A, B2, C, inv_c, x1, y0, y1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y0, x0, x1));
+    fmin_ = fminf(fmin_, edge_min(C, B2, A, inv_a, y1, x0, x1));
+    return fmin_ <= e0.z;
 }
 
 #endif  // __HIPCC__

@@ -42,7 +42,11 @@ __device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, c
             const uint32_t k = i - s_off[lo[u]];
             const ushort4 r = s_rect[lo[u]];
             const uint32_t w = (uint32_t)(r.z - r.x);
-            const uint32_t ty = k / w, tx = k - ty * w;
+            // k / w without the 25-instruction integer division: k < 2^22 (a rectangle has at most gx * gy tiles), so the
+            // float quotient of k + 0.5 is off by less than the 0.5 / w that separates it from the next integer; corrected anyway
+            uint32_t ty = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+            if (ty * w > k) --ty; else if ((ty + 1u) * w <= k) ++ty;
+            const uint32_t tx = k - ty * w;
             f(lo[u], k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, w * (uint32_t)(r.w - r.y));
         }
     }

@@ -307,8 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         // (block-cooperative expansion keeps large splats from serialising a lane)
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
-        s_r0[threadIdx.x] = ell0;
-        s_r1[threadIdx.x] = ell1;
+        tile_test_prepare(ell0, ell1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
