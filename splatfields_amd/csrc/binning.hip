@@ -7,8 +7,8 @@
 //    longest-list-first launch order of the per-tile kernels).
 //  * Each tile's list -- ~900 entries at 1 M splats / 800x800, thousands in dense scenes -- is sorted by one workgroup on
 //    the 64-bit key (depth bits << 32 | splat index), whose low half is also the payload: a key-only bitonic network held
-//    in registers (lane exchanges by DPP / v_permlane swaps, 3 LDS stages) for runs of <= 1024 entries, and a multi-way
-//    rank merge in LDS for longer lists.  A splat appears once per tile, so the key is unique and the order is exactly
+//    in registers (lane exchanges by DPP / v_permlane swaps, 3 LDS stages) for runs of <= 1024 entries, and pairwise
+//    merge-path passes in LDS for longer lists.  A splat appears once per tile, so the key is unique and the order is exactly
 //    the published "stable sort by depth, ties by splat index": a total order, independent of the arrival order of the
 //    scatter (bit-reproducible).
 // HBM traffic per instance: 8 B scatter write + 8 B sort read + 4 B sorted write, versus 6 radix passes x 24 B for a
@@ -403,7 +403,7 @@ __device__ __forceinline__ void sort_tile_regs(const Binning& b, uint32_t start,
     }
 }
 
-// forward declaration (defined below): runs of 1024 sorted by the register network + one multi-way merge pass in LDS
+// forward declaration (defined below): runs of 1024 sorted by the register network + pairwise merge passes in LDS
 template <int CAP, int THREADS, typename Emit>
 __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first, uint32_t n, uint64_t* run_key, Emit&& emit);
 
