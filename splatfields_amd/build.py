@@ -30,14 +30,40 @@ def is_stale() -> bool:
     return any((CSRC / f).stat().st_mtime > t for f in SOURCES + HEADERS)
 
 
+def strip_comments(text: str) -> str:
+    """C / C++ source without comments and without blank or indentation differences (string and character literals are kept)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                   # literal: copy up to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    lines = (" ".join(line.split()) for line in "".join(out).splitlines())
+    return "\n".join(line for line in lines if line)
+
+
 def source_hash() -> str:
-    """sha256 (first 16 hex digits) over the kernel sources and headers the library is built from: recorded counter files under
-    profiles/ carry it, and bench.py refuses them when the sources have changed since they were collected."""
+    """sha256 (first 16 hex digits) over the CODE of the kernel sources and headers the library is built from (comments and
+    layout do not count: strip_comments): recorded counter files under profiles/ carry it, and bench.py refuses them when the
+    code has changed since they were collected."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(SOURCES + HEADERS):
         h.update(f.encode())
-        h.update((CSRC / f).read_bytes())
+        h.update(strip_comments((CSRC / f).read_text()).encode())
     return h.hexdigest()[:16]
 
 

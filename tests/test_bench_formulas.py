@@ -81,3 +81,24 @@ def test_median_of_per_step_times():
     # one slow step (a box hiccup) moves the mean, not the median
     xs = [0.70] * 19 + [1.40]
     assert bench.median(xs) == 0.70 and sum(xs) / len(xs) > 0.73
+
+
+def test_source_hash_ignores_comments_and_layout(tmp_path, monkeypatch):
+    """The stamp that ties recorded counters to the kernels (build.source_hash) is taken over the code only: editing a comment or
+    re-indenting must not invalidate a profile, changing a token must."""
+    from splatfields_amd import build
+    a = "int f(int x) {\n    // add one\n    return x + 1;   /* done */\n}\nconst char* s = \"// not a comment\";\n"
+    b = "int f(int x) {\n\n  // a different remark\n  return x + 1;\n}\nconst char* s = \"// not a comment\";\n"
+    c = a.replace("x + 1", "x + 2")
+    assert build.strip_comments(a) == build.strip_comments(b) != build.strip_comments(c)
+    assert "// not a comment" in build.strip_comments(a)
+    src = tmp_path / "csrc"
+    src.mkdir()
+    monkeypatch.setattr(build, "CSRC", src)
+    monkeypatch.setattr(build, "SOURCES", ["k.hip"])
+    monkeypatch.setattr(build, "HEADERS", [])
+    hashes = []
+    for text in (a, b, c):
+        (src / "k.hip").write_text(text)
+        hashes.append(build.source_hash())
+    assert hashes[0] == hashes[1] != hashes[2]
