@@ -355,13 +355,15 @@ int sr_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long*
  * `planes_texel_major` [3, H, W, C] is written by the forward (a transposed copy: a corner becomes C contiguous floats) and
  * read again by the backward.
  * Backward: dL_dpoints [N, 3] (gather) and / or dL_dplanes [3, C, H, W] (either may be NULL).  The plane gradient is
- * accumulated in 64-bit fixed point with integer atomics -- bit-reproducible, no floating-point atomics; `fixed` holds
- * sr_triplane_fixed_bytes(C, H, W) bytes (needed only with dL_dplanes). */
-size_t sr_triplane_fixed_bytes(int channels, int height, int width);
+ * accumulated in 64-bit fixed point with integer atomics -- bit-reproducible, no floating-point atomics: the (point, plane)
+ * pairs are binned by tile of the plane and every tile is summed in LDS by one workgroup; `workspace` holds
+ * sr_triplane_backward_workspace(N, C, H, W) bytes (tile counters and the binned lists; needed only with dL_dplanes; 0 for
+ * unsupported sizes: C a multiple of 4, <= 128). */
+size_t sr_triplane_backward_workspace(int n_points, int channels, int height, int width);
 int sr_triplane_forward(int n_points, int channels, int height, int width, const float* planes, float* planes_texel_major,
                         const float* points, float* out, void* hip_stream);
 int sr_triplane_backward(int n_points, int channels, int height, int width, const float* planes_texel_major, const float* points,
-                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* fixed, void* hip_stream);
+                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* workspace, void* hip_stream);
 
 /* Diagnostics for the parity tests: byte offsets of four arrays inside the opaque buffers of a view with these sizes
  * (`instances` = the capacity the binning buffer was carved for):

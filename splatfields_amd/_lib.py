@@ -103,7 +103,7 @@ SYMBOLS = {
     "sr_resfield_compose": (C.c_int, [C.c_int, C.POINTER(SrResFieldJob), C.c_void_p, C.c_void_p]),
     "sr_resfield_backward_workspace": (C.c_size_t, [C.c_int, C.POINTER(SrResFieldJob)]),
     "sr_resfield_backward": (C.c_int, [C.c_int, C.POINTER(SrResFieldJob), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "sr_triplane_fixed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sr_triplane_backward_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "sr_triplane_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_triplane_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),

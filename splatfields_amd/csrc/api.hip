@@ -447,9 +447,8 @@ int sr_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long long*
     return check_hip(hipGetLastError(), "resfield_backward");
 }
 
-size_t sr_triplane_fixed_bytes(int channels, int height, int width) {
-    if (channels <= 0 || height <= 0 || width <= 0) return 0;
-    return ((size_t)3 * height * width * channels + 1) * sizeof(unsigned long long);
+size_t sr_triplane_backward_workspace(int n_points, int channels, int height, int width) {
+    return sr::triplane_backward_workspace(n_points, channels, height, width);
 }
 
 int sr_triplane_forward(int n_points, int channels, int height, int width, const float* planes, float* planes_texel_major,
@@ -461,13 +460,13 @@ int sr_triplane_forward(int n_points, int channels, int height, int width, const
 }
 
 int sr_triplane_backward(int n_points, int channels, int height, int width, const float* planes_texel_major, const float* points,
-                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* fixed, void* hip_stream) {
-    if (n_points < 0 || !planes_texel_major || (n_points > 0 && (!points || !dL_dout)) || (dL_dplanes && !fixed))
+                         const float* dL_dout, float* dL_dplanes, float* dL_dpoints, void* workspace, void* hip_stream) {
+    if (n_points < 0 || !planes_texel_major || (n_points > 0 && (!points || !dL_dout)) || (dL_dplanes && !workspace))
         return fail("bad arguments to sr_triplane_backward");
     const int rc = sr::launch_triplane_backward(n_points, channels, height, width, planes_texel_major, points, dL_dout, dL_dplanes, dL_dpoints,
-                                                fixed, static_cast<hipStream_t>(hip_stream));
-    if (rc == 1) return fail("sr_triplane_backward: channels must be a positive multiple of 4, height * width <= 2^30");
-    if (rc) return fail("sr_triplane_backward: clearing the accumulators failed");
+                                                workspace, static_cast<hipStream_t>(hip_stream));
+    if (rc == 1) return fail("sr_triplane_backward: channels must be a multiple of 4 in 4..128, height * width <= 2^30, 12 n_points < 2^32");
+    if (rc) return fail("sr_triplane_backward: clearing the tile counters failed");
     return check_hip(hipGetLastError(), "triplane_backward");
 }
 

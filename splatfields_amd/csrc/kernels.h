@@ -69,7 +69,8 @@ int launch_resfield_backward(int n_jobs, const SrResFieldJob* jobs, const long l
 // triplane.hip
 int launch_triplane_forward(int N, int C, int H, int W, const float* planes_chw, float* planes_hwc, const float* pts, float* out, hipStream_t st);
 int launch_triplane_backward(int N, int C, int H, int W, const float* planes_hwc, const float* pts, const float* g, float* d_planes_chw,
-                             float* d_pts, void* fixed, hipStream_t st);
+                             float* d_pts, void* workspace, hipStream_t st);
+size_t triplane_backward_workspace(int N, int C, int H, int W);
 
 // knn.hip
 size_t knn_workspace_bytes(int n);

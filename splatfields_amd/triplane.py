@@ -61,7 +61,7 @@ class _TriPlaneLookup(torch.autograd.Function):
         need_planes, need_pts = ctx.needs_input_grad
         d_planes = torch.empty(3, ch, h, w, dtype=torch.float32, device=dev) if need_planes else None
         d_pts = torch.empty(n, 3, dtype=torch.float32, device=dev) if need_pts else None
-        fixed = torch.empty(lib.sr_triplane_fixed_bytes(ch, h, w), dtype=torch.uint8, device=dev) if need_planes else None
+        fixed = torch.empty(lib.sr_triplane_backward_workspace(n, ch, h, w), dtype=torch.uint8, device=dev) if need_planes else None
         with torch.cuda.device(dev):
             _lib.check(lib.sr_triplane_backward(n, ch, h, w, _ptr(hwc), _ptr(x32), _ptr(g32), _ptr(d_planes), _ptr(d_pts), _ptr(fixed),
                                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
