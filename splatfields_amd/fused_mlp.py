@@ -40,6 +40,14 @@ def pack_layer_weight(W: torch.Tensor, n_mem: int, mem_pad: int, reg_width: int,
     return v.permute(2, 0, 3, 4, 1, 5).contiguous().reshape(-1)   # (c, mt, tl, k, m, i)
 
 
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """the tensor as contiguous float32 -- itself when it already is (the usual case: one attribute
+    test instead of three tensor methods; ~50 of these per network and step are host time the GPU waits for)"""
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t          # only its data pointer is used; autograd.Function inputs may be saved as they are
+    return t.detach().to(torch.float32).contiguous()
+
+
 class _Shape:
     """Static description of one GeneralMLP: which layers read the network input, tile counts, validity."""
 
@@ -300,8 +308,8 @@ class _FusedMLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_in, shape: _Shape, slope: float, grad_enabled: bool, *params):
         L = shape.n_layers
-        weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
-        biases = [p.detach().to(torch.float32).contiguous() for p in params[L:]]
+        weights = [_f32c(p) for p in params[:L]]
+        biases = [_f32c(p) for p in params[L:]]
         x0 = F.pad(h_in.detach().to(torch.float32), (0, shape.mem_pad - shape.d_in)).contiguous()
         # needs_input_grad reflects requires_grad of the inputs, not the grad mode (inside forward() grad mode is always off):
         # under torch.no_grad() nothing will run backward, so the [L-1, N, hidden] activation stack is neither allocated nor written
@@ -338,11 +346,11 @@ class _FusedMLPPointsFn(torch.autograd.Function):
     def forward(ctx, xyz, feat, time, shape: _Shape, slope: float, multires: int, time_multires: int, grad_enabled: bool, *params):
         lib = _lib.load()
         L = shape.n_layers
-        weights = [p.detach().to(torch.float32).contiguous() for p in params[:L]]
-        biases = [p.detach().to(torch.float32).contiguous() for p in params[L:]]
+        weights = [_f32c(p) for p in params[:L]]
+        biases = [_f32c(p) for p in params[L:]]
         dev, n = xyz.device, xyz.shape[0]
-        x32 = xyz.detach().to(torch.float32).contiguous()
-        f32 = feat.detach().to(torch.float32).contiguous() if feat is not None else None
+        x32 = _f32c(xyz)
+        f32 = _f32c(feat) if feat is not None else None
         t32 = time.detach().to(torch.float32).reshape(-1).contiguous() if time is not None else None
         n_feat = 0 if f32 is None else f32.shape[1]
         x0 = torch.empty(n, shape.mem_pad, dtype=torch.float32, device=dev)

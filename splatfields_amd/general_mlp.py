@@ -84,9 +84,8 @@ class _ResFieldCompose(torch.autograd.Function):
         if n < 1 or n > _lib.RESFIELD_MAX_JOBS:
             raise ValueError("between 1 and %d ResField layers per call" % _lib.RESFIELD_MAX_JOBS)
         dev = params[0].device
-        Ws = [p.detach().contiguous() for p in params[0::3]]
-        wts = [p.detach().contiguous() for p in params[1::3]]
-        Ms = [p.detach().contiguous() for p in params[2::3]]
+        keep = lambda t_: t_ if t_.is_contiguous() else t_.detach().contiguous()
+        Ws, wts, Ms = [keep(p) for p in params[0::3]], [keep(p) for p in params[1::3]], [keep(p) for p in params[2::3]]
         frame = frame.detach().to(device=dev, dtype=torch.int64).reshape(1).contiguous()
         outs = [torch.empty_like(W) for W in Ws]
         jobs = (_lib.SrResFieldJob * n)()
