@@ -148,6 +148,25 @@ def compose_resfield_weights(layers: Sequence["ResFieldLinear"], frame_id) -> li
     return [next(composed) if l.has_residual else l.weight for l in layers]
 
 
+class _Normalize(torch.autograd.Function):
+    """`F.normalize(x, dim=-1)` (eps 1e-12) with a five-kernel backward: autograd's own chain through norm -> clamp -> expand ->
+    div is ~12 small kernels per step for the [N, 4] rotations."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        y = x / n
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, n = ctx.saved_tensors
+        dot = (g * y).sum(dim=-1, keepdim=True)
+        # below the clamp the norm is a constant: d (x / eps) = g / eps
+        return torch.where(n > 1e-12, g - y * dot, g) / n
+
+
 _OUT_ACTIVATIONS = {
     "none": lambda x: x,
     "sigmoid": torch.sigmoid,
@@ -157,7 +176,7 @@ _OUT_ACTIVATIONS = {
     "softplus": nn.functional.softplus,
     "softmax": lambda x: nn.functional.softmax(x, dim=-1),
     "elu": nn.functional.elu,
-    "normalize": nn.functional.normalize,
+    "normalize": _Normalize.apply,
     "leaky_relu": nn.functional.leaky_relu,
 }
 _SLOPES = {"leaky_relu": 0.01, "relu": 0.0}

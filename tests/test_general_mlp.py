@@ -120,3 +120,21 @@ def test_reference_checkpoint_round_trip(hip_device, tmp_path):
         for frame in (0, 7, 11):
             assert torch.equal(a(xyz, feat, frame_id=frame), b(xyz, feat, frame_id=torch.tensor(frame, device=hip_device)))
         assert not torch.equal(a(xyz, feat, frame_id=0), a(xyz, feat, frame_id=1))
+
+
+def test_normalize_activation_matches_torch():
+    """the 'normalize' output activation (rotations, reference utils/time_utils.py:174) has its own compact backward: same values
+    and gradients as F.normalize, also at and below the eps clamp"""
+    import torch.nn.functional as F
+    from splatfields_amd.general_mlp import _Normalize
+    torch.manual_seed(3)
+    x = torch.randn(500, 4, dtype=torch.float64)
+    x[3] = 0.0
+    x[4] = 1e-14
+    x.requires_grad_(True)
+    g = torch.randn(500, 4, dtype=torch.float64)
+    a = _Normalize.apply(x)
+    ga, = torch.autograd.grad(a, x, g)
+    b = F.normalize(x, dim=-1)
+    gb, = torch.autograd.grad(b, x, g)
+    assert torch.equal(a, b) and (ga - gb).abs().max().item() <= 1e-12 * gb.abs().max().item()
