@@ -167,7 +167,7 @@ class SplatFields(nn.Module):
         else:
             feat, tk = self.extract_features(xyz_in, t), {}
         if self.deform_weight > 0:
-            xyz_can = xyz_in + self.deform_weight * self.mlp_deform(xyz_in, feat, frame_id=frame_id, **tk)
+            xyz_can = torch.add(xyz_in, self.mlp_deform(xyz_in, feat, frame_id=frame_id, **tk), alpha=self.deform_weight)   # one kernel
         else:
             xyz_can = xyz_in
         geo_xyz, geo_feat = (feat, None) if self.geo_model_disable_pts else (xyz_can, feat)
