@@ -30,26 +30,32 @@ from .fused_mlp import PointLinear
 from .general_mlp import GeneralMLP, positional_encoding
 
 
-def _cross(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    return torch.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], dim=-1)
+def _se3_parts(w: torch.Tensor, v: torch.Tensor, theta: torch.Tensor):
+    """rotation R [N, 3, 3] and translation p [N, 3] of exp of the screw (w, v) * theta (see se3_transform), in ~20 batched
+    kernels: the cross products are `torch.linalg.cross` calls, [w] is minus the cross product of w with the three basis
+    vectors (row j of cross(w, e_j) is column j of [w], and [w] is antisymmetric)."""
+    n = w.shape[0]
+    s, c = torch.sin(theta), torch.cos(theta)                    # [N, 1]
+    eye = torch.eye(3, device=w.device, dtype=w.dtype)
+    skew = -torch.linalg.cross(w[:, None, :].expand(n, 3, 3), eye.expand(n, 3, 3), dim=-1)
+    ww = (w * w).sum(-1, keepdim=True)
+    skew2 = w[:, :, None] * w[:, None, :] - ww[:, :, None] * eye
+    omc = 1.0 - c
+    R = eye + s[:, :, None] * skew + omc[:, :, None] * skew2
+    wv = torch.linalg.cross(w, v, dim=-1)
+    wwv = torch.linalg.cross(w, wv, dim=-1)
+    p = theta * v + omc * wv + (theta - s) * wwv
+    return R, p
 
 
 def se3_transform(w: torch.Tensor, v: torch.Tensor, theta: torch.Tensor):
     """exp of the screw (w, v) * theta as the reference builds it (utils/rigid_utils.py:40-84; Modern Robotics 3.51 / 3.88),
     without assuming |w| = 1 (the reference adds 1e-5 to the normalised axis):  R = I + sin(theta) [w] + (1 - cos(theta)) [w]^2,
     p = (theta I + (1 - cos(theta)) [w] + (theta - sin(theta)) [w]^2) v, with [w]^2 = w w^T - |w|^2 I.  -> [N, 4, 4]."""
-    n = w.shape[0]
-    s, c = torch.sin(theta), torch.cos(theta)                    # [N, 1]
-    zeros = torch.zeros(n, device=w.device, dtype=w.dtype)
-    skew = torch.stack([zeros, -w[:, 2], w[:, 1], w[:, 2], zeros, -w[:, 0], -w[:, 1], w[:, 0], zeros], dim=-1).view(n, 3, 3)
-    eye = torch.eye(3, device=w.device, dtype=w.dtype).expand(n, 3, 3)
-    skew2 = w[:, :, None] * w[:, None, :] - (w * w).sum(-1)[:, None, None] * eye
-    R = eye + s[:, :, None] * skew + (1.0 - c)[:, :, None] * skew2
-    wv = _cross(w, v)
-    wwv = _cross(w, wv)
-    p = theta * v + (1.0 - c) * wv + (theta - s) * wwv
-    bottom = torch.cat([torch.zeros(n, 1, 3, device=w.device, dtype=w.dtype), torch.ones(n, 1, 1, device=w.device, dtype=w.dtype)], dim=-1)
-    return torch.cat([torch.cat([R, p[:, :, None]], dim=-1), bottom], dim=1)   # (no host -> device copy: safe under graph capture)
+    R, p = _se3_parts(w, v, theta)
+    bottom = torch.zeros(1, 1, 4, device=w.device, dtype=w.dtype)   # (device-side fill: no host -> device copy, safe under graph capture)
+    bottom[..., 3] = 1.0
+    return torch.cat([torch.cat([R, p[:, :, None]], dim=-1), bottom.expand(w.shape[0], 1, 4)], dim=1)
 
 
 def dct_basis(num_basis: int, num_frames: int) -> torch.Tensor:
