@@ -245,7 +245,7 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, st);
 }
 
-int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, const void* binning,
+int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
                 long long instances, long long instances_rendered, const void* image, const int* radii,
                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
                 const SrGrads* grads, void* hip_stream) {
@@ -263,7 +263,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, co
     const sr::SplatsK s = make_splats(splats);
     sr::Geom g; sr::Binning b; sr::Image im;
     sr::carve_geom(const_cast<void*>(geom), s.N, v.H, v.W, &g);
-    sr::carve_binning(const_cast<void*>(binning), instances, &b);
+    sr::carve_binning(binning, instances, &b);   // Binning::reached is written by the backward blend (splatraster.h)
     sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
     float* slots = static_cast<float*>(scratch);
     {

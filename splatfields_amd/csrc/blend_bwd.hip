@@ -53,6 +53,9 @@ static_assert(SR_BWD_CAP >= 256 && SR_BWD_CAP_DEPTH >= 256, "one quad's entries 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SR_BWD_DIAG
+#define SR_BWD_DIAG 0   // timing experiments (wrong results): 1 no replay, 2 no scatter / gather, 4 no chunk gathers, 8 no slot stores
+#endif
 #ifdef SR_BWD_STATS
 // diagnostic build only (bench.py's pairs_evaluated / pairs_blended figures): [0] list entries tested, [1] (quad, entry)
 // pairs, [2] buckets, [3] (pixel, entry) pairs evaluated, [4] pairs blended (alpha >= 1/255 and not behind the pixel's
@@ -166,10 +169,12 @@ __device__ __forceinline__ BwdEntry load_entry(const Geom& g, const uint32_t* id
     e.pos = pos;
     e.c = *reinterpret_cast<const float2*>(rec);
     e.r1 = rec[1]; e.r2 = rec[2];
-    const float4 r3 = rec[3];   // (tile rect origin, rect width): the instance index = the splat's first instance + the tile's
-                                // row-major position in its rect
+    const float4 r3 = rec[3];   // (tile rect origin, rect width, first instance relative to the splat's 256-splat sub-batch): the
+                                // instance index = the splat's first instance + the tile's row-major position in its rect
     const uint32_t rect_xy = __float_as_uint(r3.x), rect_w = __float_as_uint(r3.y);
-    e.inst = g.offsets[id] + (ty - (rect_xy >> 16)) * rect_w + (tx - (rect_xy & 0xffffu));
+    // block_offsets is a 4 B x N / 256 table (16 KB at 1 M splats: cache resident); the per-splat `offsets` array would cost a
+    // line of memory traffic per list entry for 4 useful bytes
+    e.inst = g.block_offsets[id >> 8] + __float_as_uint(r3.z) + (ty - (rect_xy >> 16)) * rect_w + (tx - (rect_xy & 0xffffu));
     e.qm = qms[pc];
     return e;
 }
@@ -258,37 +263,119 @@ struct QuadCtx {
 // One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
 // the "colour behind . g" of every pixel from bucket to bucket: an UP bucket (entries back to front in lanes 0..15) takes
 // them from lane 0 and leaves them in lane 15, a DOWN bucket (entries in lanes 15..0) the other way round.
+//
+// Written STAGE-major, not column-major: every stage is applied to the four pixel columns before the next stage starts.  One
+// column's chain is ~35 DEPENDENT instructions (exponent -> v_exp -> select -> v_rcp -> a 5-deep DPP product scan -> a 5-deep
+// DPP sum scan -> MFMA), and a wavefront issues in order: written column by column (round 3) the compiler kept that order,
+// the chain's latency (~8 cycles per dependent VALU instruction, two wait states in front of every DPP read of a fresh
+// result) was exposed on every instruction, and the replay ran at the speed of its dependency chain, not of the VALU
+// (measured: 16 % fewer instructions gave no time back).  Four independent chains side by side fill those gaps.
+// The product scan is inline assembly (the compiler only fuses DPP moves whose fill value is 0): its four columns are
+// interleaved inside ONE statement, so consecutive levels of a column are three instructions apart -- the two wait states a
+// DPP read needs after the VALU write of its source come for free, one s_nop per statement covers the statement's first read.
+#define SR_DPP_MUL4(ctrl) \
+    "v_mul_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
+    "v_mul_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+template <bool UP> __device__ __forceinline__ void row_scan_mul4(float (&x)[4]) {
+#ifdef SR_BWD_SCAN_SHFL
+    for (int t = 0; t < 4; ++t) x[t] = row_scan_mul<UP>(x[t]);
+#else
+    if (UP) asm("s_nop 1\n\t" SR_DPP_MUL4("row_shr:1") SR_DPP_MUL4("row_shr:2") SR_DPP_MUL4("row_shr:4") SR_DPP_MUL4("row_shr:8")
+                : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else asm("s_nop 1\n\t" SR_DPP_MUL4("row_shl:1") SR_DPP_MUL4("row_shl:2") SR_DPP_MUL4("row_shl:4") SR_DPP_MUL4("row_shl:8")
+             : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#endif
+}
+#define SR_DPP_ADD4(ctrl) \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// the sum scan the same way (left to the compiler, its scheduler puts the four columns' scans one after the other again to
+// save registers, with wait states between the levels)
+template <bool UP> __device__ __forceinline__ void row_scan_add4(float (&x)[4]) {
+#ifdef SR_BWD_SCAN_SHFL
+    for (int t = 0; t < 4; ++t) x[t] = row_scan_add<UP>(x[t]);
+#else
+    if (UP) asm("s_nop 1\n\t" SR_DPP_ADD4("row_shr:1") SR_DPP_ADD4("row_shr:2") SR_DPP_ADD4("row_shr:4") SR_DPP_ADD4("row_shr:8")
+                : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else asm("s_nop 1\n\t" SR_DPP_ADD4("row_shl:1") SR_DPP_ADD4("row_shl:2") SR_DPP_ADD4("row_shl:4") SR_DPP_ADD4("row_shl:8")
+             : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#endif
+}
+
 template <bool UP, bool HAS_D>
 __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e, float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
     const float dy = e.cy - c.pyf;
     const float4 f = make_float4(e.p, e.s, e.q, e.nlo);
+    float oG[4], oGc[4], alpha[4], ginv[4], x[4], T[4], wgt[4], cgv[4], z[4], y[4];
+    // opacity * G of the four pixels of this row: the forward's instruction sequence (pair_alpha_unclamped), so both passes
+    // make the same alpha >= 1/255 decisions
+#pragma unroll
+    for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_unclamped(e.cx - c.pxf[t], dy, f);
+#if SR_BWD_DIAG & 64
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const float tt = f.x * fmaf(f.y, dy, e.cx - c.pxf[t]); oG[t] = fmaf(tt, tt, f.w) * 0.001f; }   // timing experiment: no v_exp
+#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const float dx = e.cx - c.pxf[t];
-        const float oG = pair_alpha_unclamped(dx, dy, f);   // opacity * G: the forward's instruction sequence
-        const bool hit = (oG >= kAlphaMin) && (e.pos < c.last[t]);
-        const float oGc = hit ? oG : 0.0f;                   // everyone else: alpha = G = 0, transparent to the scans
+        const bool hit = (oG[t] >= kAlphaMin) && (e.pos < c.last[t]);
+        oGc[t] = hit ? oG[t] : 0.0f;                     // everyone else: alpha = G = 0, transparent to the scans
 #ifdef SR_BWD_STATS
         { const int nh = __popcll(__builtin_amdgcn_ballot_w64(hit)); if (lane == 0) SR_STAT_ADD(4, nh); }
 #endif
-        const float alpha = __builtin_amdgcn_fmed3f(oGc, 0.0f, kAlphaMax);
-        const float ginv = __builtin_amdgcn_rcpf(1.0f - alpha);
-        // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
-        const float T = row_scan_mul<UP>(shift_in_carry<UP>(ST[t], ginv)) * ginv;
-        ST[t] = T;   // last lane of the scan: behind the next bucket
-        const float wgt = alpha * T;
-        float cgv = c.gA[t];   // the alpha channel's "colour" is 1 for every splat
-        if (HAS_D) cgv = fmaf(e.depth, c.gD[t], cgv);
-        cgv = fmaf(e.b, c.gB[t], cgv); cgv = fmaf(e.g, c.gG[t], cgv); cgv = fmaf(e.r, c.gR[t], cgv);
-        const float z = wgt * cgv;
-        // (colour accumulated behind entry n, incl. background) . upstream gradient
-        const float behind = row_scan_add<UP>(shift_in_carry<UP>(SB[t], z));
-        SB[t] = behind + z;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) alpha[t] = __builtin_amdgcn_fmed3f(oGc[t], 0.0f, kAlphaMax);
+#pragma unroll
+#if SR_BWD_DIAG & 64
+    for (int t = 0; t < 4; ++t) ginv[t] = 1.0f + alpha[t];   // timing experiment: no v_rcp
+#else
+    for (int t = 0; t < 4; ++t) ginv[t] = __builtin_amdgcn_rcpf(1.0f - alpha[t]);
+#endif
+    // (colour . upstream gradient) of every pixel: independent of the chain above, fills its gaps
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v = c.gA[t];   // the alpha channel's "colour" is 1 for every splat
+        if (HAS_D) v = fmaf(e.depth, c.gD[t], v);
+        v = fmaf(e.b, c.gB[t], v); v = fmaf(e.g, c.gG[t], v); v = fmaf(e.r, c.gR[t], v);
+        cgv[t] = v;
+    }
+    // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x[t] = shift_in_carry<UP>(ST[t], ginv[t]);
+#if !(SR_BWD_DIAG & 32)
+    row_scan_mul4<UP>(x);
+#endif
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { T[t] = x[t] * ginv[t]; ST[t] = T[t]; }   // last lane of the scan: behind the next bucket
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { wgt[t] = alpha[t] * T[t]; z[t] = wgt[t] * cgv[t]; }
+    // (colour accumulated behind entry n, incl. background) . upstream gradient
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = shift_in_carry<UP>(SB[t], z[t]);
+#if !(SR_BWD_DIAG & 32)
+    row_scan_add4<UP>(y);
+#endif
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float behind = y[t];
+        SB[t] = behind + z[t];
         // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
-        const float dLa = T * cgv - ginv * behind;
-        const float g1 = oGc * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
+        const float dLa = T[t] * cgv[t] - ginv[t] * behind;
+        const float g1 = oGc[t] * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
+#if SR_BWD_DIAG & 16
+        D1[t] += c.A1[t] * g1; D2[t] += c.A2[t] * wgt[t];   // timing experiment: no MFMA
+#else
+        // (Both contractions into ONE accumulator, the four that only need the weights issued right behind the product scan and
+        // the sums stored a bucket later -- so that no matrix instruction is waited for -- was measured in round 4: 0.2502 vs
+        // 0.2477 ms, not better: what the matrix instructions cost, 0.037 of 0.18 ms in a build without them, is the pipe time
+        // itself -- 8 x 32 cycles per bucket on the SIMD's one matrix pipe, shared by its three wavefronts.)
         D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A1[t], g1, D1, 0, 0, 0);
-        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A2[t], wgt, D2, 0, 0, 0);
+        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A2[t], wgt[t], D2, 0, 0, 0);
+#endif
     }
     (void)lane;
 }
@@ -457,6 +544,9 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             // ---------------- (C) scatter the records into the quads' slot runs ----------------
             {
                 uint32_t m = qm & pmask;
+#if SR_BWD_DIAG & 2
+                m = 0u;   // timing experiment: no record scatter
+#endif
                 while (m) {
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
@@ -482,6 +572,9 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 const int qy = q >> 2, qx = q & 3;
                 const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[par][q]);
                 if (len == 0) continue;
+#if SR_BWD_DIAG & 1
+                continue;   // timing experiment: no replay
+#endif
                 const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[par][q]);
                 const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
                 QuadCtx c;
@@ -558,6 +651,9 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             // ---------------- (E) add up the quads' sums of every entry (ascending quad index: fixed summation order) ----------
             if (cur.pos >= 0) {
                 uint32_t m = qm & pmask;
+#if SR_BWD_DIAG & 2
+                m = 0u;   // timing experiment: no gather of the sums
+#endif
                 while (m) {
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
@@ -581,9 +677,17 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
         const float2 centre = cur.c;
         const size_t inst = cur.inst;
         const bool has_entry = cur.pos >= 0;
+#if SR_BWD_DIAG & 4
+        if (hi > 0) cur.pos = hi - 1 - tid;   // timing experiment: no gather for the following chunks
+#else
         if (hi > 0) cur = load_entry(g, ids, qms, hi - 1 - tid, (uint32_t)tx, (uint32_t)ty);   // uniform condition
+#endif
         // shift the moments to the splat centre and store the instance's gradient slot
+#if SR_BWD_DIAG & 8
+        if (has_entry && s0.x == 12345.678f) {   // timing experiment: (practically) no slot stores
+#else
         if (has_entry) {
+#endif
             // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
             const float ox = centre.x - (tx0f + 7.5f), oy = centre.y - (ty0f + 7.5f);
             const float M0 = s0.x, MX = s0.y, MY = s0.z, MXX = s0.w, MXY = s1.x, MYY = s1.y;
@@ -591,9 +695,9 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             const float Sxx = fmaf(ox, Sx - MX, MXX);               // ox^2 M0 - 2 ox MX + MXX
             const float Syy = fmaf(oy, Sy - MY, MYY);
             const float Sxy = fmaf(ox, Sy, MXY) - oy * MX;          // ox oy M0 - ox MY - oy MX + MXY
-            slot4[inst * 3] = make_float4(M0, Sx, Sy, Sxx);
-            slot4[inst * 3 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
-            slot4[inst * 3 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
+            slot4[inst * kSlotF4] = make_float4(M0, Sx, Sy, Sxx);
+            slot4[inst * kSlotF4 + 1] = make_float4(Sxy, Syy, s1.z, s1.w);
+            slot4[inst * kSlotF4 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
             b.reached[inst] = 1;
         }
         SR_PHASE(7);   // (E) combine

@@ -189,7 +189,15 @@ inline size_t carve_image(void* base, int H, int W, Image* im) {
 // (S0, Sx, Sy, Sxx | Sxy, Syy, dr, dg | db, ddepth, pad, pad)
 // Only the instances the forward reached (list position in front of the stop of the tile's last pixel) are written by the
 // backward blend and read by k_preprocess_backward; Binning::reached says which.
-constexpr int kSlotFloats = 12;
+// Slot stride = kSlotF4 quarters of 16 bytes.  Memory is written and fetched in 64-byte sectors, and a 48-byte stride puts half
+// of the slots across two of them (backward blend: WRITE_SIZE 168 MB for 82 MB of slots).  A 64-byte stride was measured
+// (round 4, SR_SLOT_F4=4): the backward blend does not care (0.2556 vs 0.2558 ms), and k_preprocess_backward gets SLOWER
+// (0.0978 vs 0.0945 ms) -- it reads a splat's consecutive instances, which the 48-byte stride packs into fewer sectors.
+#ifndef SR_SLOT_F4
+#define SR_SLOT_F4 3
+#endif
+constexpr int kSlotF4 = SR_SLOT_F4;
+constexpr int kSlotFloats = 4 * kSlotF4;
 
 
 // ---- per-view constants, passed to kernels by value ----------------------------------------
@@ -303,7 +311,12 @@ __device__ __forceinline__ float pair_alpha_unclamped(float dx, float dy, const 
     return __builtin_amdgcn_exp2f(-w);   // = opacity * G
 }
 // Q' = conic * log2(e) back from the factors (the support test works on the quadratic form)
+// (The tile-reach decision built on this -- tile_test_prepare / tile_reached / edge_min -- is evaluated by k_count_tiles and
+// again by k_emit, and the two MUST agree bit for bit, or a chunk's piece of a tile segment overflows into its neighbour's:
+// floating-point contraction is switched off inside these functions, so that the result does not depend on which
+// multiply-adds the compiler fuses in each inlining context.)
 __device__ __forceinline__ void conic_from_factors(const float4 f, float& A, float& B, float& C) {
+#pragma clang fp contract(off)
     A = 2.0f * f.x * f.x;
     B = f.y * A;
     C = fmaf(2.0f * f.z, f.z, f.y * B);
@@ -313,6 +326,7 @@ __device__ __forceinline__ void conic_from_factors(const float4 f, float& A, flo
 // the splat's alpha can reach 1/255, i.e. min over the box of d^T Q d <= tau?  The minimum of a convex
 // quadratic over a box is at the centre if it is inside, else on one of the 4 edges (1-D clamped minima).
 __device__ __forceinline__ float edge_min(float a, float b2, float c, float inv_c, float fixed, float lo, float hi) {
+#pragma clang fp contract(off)
     // min over t in [lo,hi] of a*fixed^2 + b2*fixed*t + c*t^2   (b2 = 2B).  The minimiser only needs to be
     // approximately right (the value is evaluated exactly at it; the error is second order), so 1/c is v_rcp_f32.
     const float t = fminf(hi, fmaxf(lo, -0.5f * b2 * fixed * inv_c));
@@ -354,12 +368,14 @@ constexpr uint32_t kCullMinTiles = SR_CULL_MIN_TILES;
 // (centre x, centre y, threshold, A), e1 = (2 B, C, 1 / A, 1 / C) of the quadratic form; tile_reached then costs the four
 // edge minima only.  A splat that can never be seen has threshold < 0.
 __device__ __forceinline__ void tile_test_prepare(const float4 r0, const float4 r1, float4& e0, float4& e1) {
+#pragma clang fp contract(off)
     float A, B, C;
     conic_from_factors(r1, A, B, C);
     e0 = make_float4(r0.x, r0.y, r0.z > 0.0f ? r0.z * 1.002f + 0.03f : -1.0f, A);
     e1 = make_float4(2.0f * B, C, __builtin_amdgcn_rcpf(A), __builtin_amdgcn_rcpf(C));
 }
 __device__ __forceinline__ bool tile_reached(const float4 e0, const float4 e1, uint32_t tile_x, uint32_t tile_y) {
+#pragma clang fp contract(off)
     if (!(e0.z > 0.0f)) return false;
     const float x0 = (float)(tile_x * kTile) - e0.x, x1 = x0 + (float)(kTile - 1);  // the tile's pixel-centre box relative to the centre
     const float y0 = (float)(tile_y * kTile) - e0.y, y1 = y0 + (float)(kTile - 1);

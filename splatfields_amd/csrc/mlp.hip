@@ -505,6 +505,13 @@ __global__ void __launch_bounds__(kBlock) k_resfield_compose(const ResFieldK P) 
     const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
     if (4 * j4 >= J.count) return;
     const long long f = *P.frame;
+    if (f < 0 || f >= (long long)J.capacity) {
+        // the reference's `mat[frame_id]` raises IndexError here; a kernel cannot, and reading weights_t out of bounds would
+        // compose garbage silently: poison the weights instead, so that the network's outputs are NaN from this step on
+        const float nan = __builtin_nanf("");
+        reinterpret_cast<float4*>(J.out)[j4] = make_float4(nan, nan, nan, nan);
+        return;
+    }
     const float* coeff = J.weights_t + (size_t)f * J.rank;
     const int q = J.count >> 2;
     const float4* M = reinterpret_cast<const float4*>(J.matrix_t) + j4;
@@ -531,10 +538,13 @@ __global__ void __launch_bounds__(kBlock) k_resfield_backward(const ResFieldK P)
     if (blockIdx.x * kRfPerBlock >= J.count) return;   // whole workgroup
     const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
     const bool in = 4 * j4 < J.count;
-    const long long f = *P.frame;
+    const long long f_raw = *P.frame;
+    const bool f_ok = f_raw >= 0 && f_raw < (long long)J.capacity;   // out of range: the forward poisoned W_eff with NaN (above);
+    const long long f = f_ok ? f_raw : 0;                             //   here: no out-of-bounds read, NaN gradients
     const float* coeff = J.weights_t + (size_t)f * J.rank;
     const int q = J.count >> 2;
-    const float4 g = in ? reinterpret_cast<const float4*>(J.d_out)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g = in ? reinterpret_cast<const float4*>(J.d_out)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!f_ok) g.x = g.y = g.z = g.w = __builtin_nanf("");
     for (int k = 0; k < J.rank; ++k) {
         float dot = 0.0f;
         if (in) {

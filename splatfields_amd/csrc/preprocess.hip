@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     const float* pm = v.projmatrix;
     uint32_t touched = 0, depth_bits = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
-    float4 ell0 = make_float4(0.f, 0.f, -1.f, 0.f), ell1 = ell0;
+    float4 ell0 = make_float4(0.f, 0.f, -1.f, 0.f), ell1 = ell0, rec2 = ell0;
+    uint32_t rect_bits = 0;
+    bool write_rec = false;
 
     // issue this splat's own loads first, then the staged SH block: everything is in flight together
     float3 p = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
@@ -274,20 +276,15 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         if (rgb.y < 0.f) { flags |= kFlagClampG; rgb.y = 0.f; }
                         if (rgb.z < 0.f) { flags |= kFlagClampB; rgb.z = 0.f; }
                     }
-                    float4* rec = g.rec + 4 * (size_t)idx;
                     ell0 = make_float4(px, py, tau > 0.0f ? tau * kLog2e : -1.0f, pv.z);
-                    rec[0] = ell0;
                     depth_bits = __float_as_uint(pv.z);
                     // exponent factors (common.h, pair_alpha_unclamped): all well conditioned, c >= 0.3 by the dilation
                     const float inv_c = 1.0f / c;
                     ell1 = make_float4(sqrtf(0.5f * kLog2e * c * det_inv), -b * inv_c, sqrtf(0.5f * kLog2e * inv_c),
                                        opac > 0.0f ? -__log2f(opac) : 0.0f);
-                    rec[1] = ell1;
-                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, pv.z);  // the blend kernels read the depth with the colour: one 16-byte LDS read
-                    // q3 carries the tile rect (the backward derives a (splat, tile) pair's instance index from it).  Writing the
-                    // whole 64-byte line also matters by itself: a line with a 16-byte hole leaves the L2 as a masked
-                    // partial write, which costs more than the 16 bytes (0.087 -> 0.078 ms for this kernel).
-                    rec[3] = make_float4(__uint_as_float((uint32_t)xmin | ((uint32_t)ymin << 16)), __uint_as_float((uint32_t)(xmax - xmin)), 0.f, 0.f);
+                    rec2 = make_float4(rgb.x, rgb.y, rgb.z, pv.z);  // the blend kernels read the depth with the colour: one 16-byte LDS read
+                    rect_bits = (uint32_t)xmin | ((uint32_t)ymin << 16);
+                    write_rec = true;   // the record is stored behind the sub-batch scan below (its fourth quarter needs the scan)
                 }
             }
         }
@@ -302,6 +299,18 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     uint32_t total;
     const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+    if (write_rec) {
+        // The 64-byte record, written whole (a line with a 16-byte hole leaves the L2 as a masked partial write, which costs
+        // more than the 16 bytes: 0.087 -> 0.078 ms for this kernel).  q3 = (tile rect origin, rect width, first instance of
+        // the splat RELATIVE to its 256-splat sub-batch, 0): the backward blend derives a (splat, tile) pair's instance index
+        // from it as block_offsets[splat >> 8] + q3.z + position of the tile in the rect -- a 16 KB table that lives in the
+        // caches instead of a 4-byte gather per list entry into the 4 MB `offsets` array (one line of HBM traffic each).
+        float4* rec = g.rec + 4 * (size_t)idx;
+        rec[0] = ell0;
+        rec[1] = ell1;
+        rec[2] = rec2;
+        rec[3] = make_float4(__uint_as_float(rect_bits), __uint_as_float((uint32_t)(rect.z - rect.x)), __uint_as_float(excl), 0.f);
+    }
     if constexpr (COUNT_ATOMIC) {
         // fallback for very large images: per-tile counts with global atomics
         // (block-cooperative expansion keeps large splats from serialising a lane)
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             for (int k = 0; k < 10; ++k) part[k] = 0.f;
             for (uint32_t i = lane; i < c; i += 64u) {
                 if (!reached[f + i]) continue;  // never written by the backward blend: contributes nothing
-                const float4* sl = sl_all + (size_t)(f + i) * 3;
+                const float4* sl = sl_all + (size_t)(f + i) * kSlotF4;
                 const float4 a = sl[0], b4 = sl[1], c4 = sl[2];
                 part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
                 part[4] += b4.x; part[5] += b4.y; part[6] += b4.z; part[7] += b4.w;
@@ -441,11 +450,11 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             }
         }
         if (vis_in && !big) {
-            const float4* sl = sl_all + (size_t)first_in * 3;
+            const float4* sl = sl_all + (size_t)first_in * kSlotF4;
             for (uint32_t i = 0; i < cnt_in; ++i) {
                 const bool hit = i < 4u ? ((reached4 >> (8 * i)) & 0xffu) != 0u : reached[first_in + i] != 0;
                 if (!hit) continue;
-                const float4 a = sl[3 * i], b4 = sl[3 * i + 1], c4 = sl[3 * i + 2];
+                const float4 a = sl[kSlotF4 * i], b4 = sl[kSlotF4 * i + 1], c4 = sl[kSlotF4 * i + 2];
                 sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
                 sum[4] += b4.x; sum[5] += b4.y; sum[6] += b4.z; sum[7] += b4.w;
                 sum[8] += c4.x; sum[9] += c4.y;

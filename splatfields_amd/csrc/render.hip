@@ -197,6 +197,9 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                 const bool ok = el < cnt && ((uint32_t)s_qm[buf][el < cnt ? el : 0] & my_quads) != 0u;
 #endif
                 uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+#if defined(SR_FWD_DIAG) && (SR_FWD_DIAG & 1)
+                m = 0ull;   // timing experiment: staging, masks and barriers only
+#endif
                 const uint32_t pos0 = (base - start) + (uint32_t)c;
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     __shared__ float4 s_r0[kBwdBatch + 1];
     __shared__ float4 s_r1[kBwdBatch + 1];
     __shared__ float4 s_r2[kBwdBatch + 1];
-    __shared__ float4 s_acc[4][kBwdBatch][kSlotFloats / 4];
+    __shared__ float4 s_acc[4][kBwdBatch][3];
     __shared__ uint32_t s_max[4];
 
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
             const uint32_t id = b.sorted_id[pos];
             const float4* rec = g.rec + 4 * (size_t)id;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-            const uint32_t inst_first = g.offsets[id];
+            const uint32_t inst_first = g.block_offsets[id >> 8] + __float_as_uint(r3.z);   // see load_entry (blend_bwd.hip)
             s_r0[threadIdx.x] = r0;
             s_r1[threadIdx.x] = r1;
             s_r2[threadIdx.x] = r2;
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         }
         {
             float4* acc = &s_acc[0][0][0];
-            for (int i = threadIdx.x; i < 4 * kBwdBatch * (kSlotFloats / 4); i += kBlock) acc[i] = zero4;
+            for (int i = threadIdx.x; i < 4 * kBwdBatch * 3; i += kBlock) acc[i] = zero4;
         }
         __syncthreads();
         if (wmax > top - cnt) {
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const float4 a0 = s_acc[0][e][q], a1 = s_acc[1][e][q], a2 = s_acc[2][e][q], a3 = s_acc[3][e][q];
-                slot4[inst * 3 + q] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                slot4[inst * kSlotF4 + q] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
                                                   (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
             }
             b.reached[inst] = 1;

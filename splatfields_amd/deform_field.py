@@ -2,8 +2,10 @@
 kernels (splatfields_amd/general_mlp.py).
 
 Same constructor keywords, same `forward(xyz_in, t)` -> dict(scales, opacity, rotations, rgb | rgb_fnc, flow, means3D), same
-parameter names (`mlp_deform.net.<i>...`, `mlp_refine_feat.<i>...`, `mlp_flow_head.branch_w...`, `encoder....`), so
-`deform.pth` checkpoints (reference scene/deform_model.py:36-47) load with `load_state_dict`.
+parameter names (`mlp_deform.net.<i>...`, `mlp_refine_feat.<i>...`, `mlp_flow_head.branch_w...`), so the MLP / flow-head part of a
+`deform.pth` checkpoint (reference scene/deform_model.py:36-47) loads with `load_state_dict`.  NOT drop-in for the reference's
+DEFAULT encoder: its checkpoints carry the plane generator's weights (`encoder.subs.*`), which only load when the caller supplies
+that generator (below); `load_state_dict` says so instead of failing on missing / unexpected keys.
 
 The tri-plane feature encoder (reference scene/tripFields.py:383-436) is `splatfields_amd.triplane.TriPlaneSampler`: the
 per-point lookup (three `grid_sample`s + cat) runs on HIP kernels, forward and backward.  With the reference's default
@@ -109,6 +111,12 @@ class SplatFields(nn.Module):
         if encoder is None and self.encoder_type in ["VarTriPlaneEncoder"]:
             from .triplane import TriPlaneSampler
             ea = kwargs.get("encoder_args", {}) or {}
+            ignored = sorted(k for k in ea if k not in ("out_ch", "noise_res", "fuse_mode", "plane_source"))
+            if ignored:
+                import warnings
+                warnings.warn("SplatFields: encoder_args %s configure the reference's plane GENERATOR (scene/tripFields.py:176-204), which "
+                              "is not part of this package -- they are ignored by the decoder-free TriPlaneSampler; pass the generator as "
+                              "encoder_args['plane_source'] or a whole encoder as encoder=" % ignored, stacklevel=2)
             encoder = TriPlaneSampler(out_ch=ea.get("out_ch", 16), resolution=16 * ea.get("noise_res", 20),
                                       fuse_mode=ea.get("fuse_mode", "cat"), plane_source=ea.get("plane_source"))
         if encoder is not None:
@@ -146,6 +154,20 @@ class SplatFields(nn.Module):
             self.mlp_flow = mlp("flow", kwargs.get("flow_w", 128), 128, 6, [3], kwargs.get("flow_multires", 6), "none")
             self.mlp_flow_head = FlowHead(W=self.mlp_flow.out_features, flow_model=kwargs.get("flow_model", "se3"),
                                           num_basis=kwargs.get("dct_basis", 4), n_frames=n_frames)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """`nn.Module.load_state_dict`, plus one loud check: a reference default-config checkpoint holds the weights of its
+        time-conditioned plane generators (`encoder.subs.*`, scene/tripFields.py:383-428).  The decoder-free sampler has no place
+        for them, and silently training its own free planes instead would be a different model."""
+        gen_keys = [k for k in state_dict if k.startswith("encoder.subs.")]
+        own = getattr(self, "encoder", None)
+        if gen_keys and own is not None and not any(k.startswith("encoder.subs.") for k in self.state_dict()):
+            raise RuntimeError(
+                "this checkpoint carries the reference's tri-plane GENERATOR (%d `encoder.subs.*` tensors, e.g. %r), but this SplatFields "
+                "was built with the decoder-free TriPlaneSampler (planes are a free parameter, they ignore frame_id).  Build it with the "
+                "reference's encoder -- SplatFields(encoder=<VarTriPlaneEncoder instance>) or encoder_args['plane_source'] -- to load it."
+                % (len(gen_keys), gen_keys[0]))
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def _time2frame_id(self, t):
         return torch.round(t * (self.n_frames - 1))

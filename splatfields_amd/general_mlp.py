@@ -140,6 +140,15 @@ def compose_resfield_weights(layers: Sequence["ResFieldLinear"], frame_id) -> li
                   for l in res) and len(res) <= _lib.RESFIELD_MAX_JOBS
     if not fusable:
         return [l.effective(frame_id) for l in layers]
+    if not torch.is_tensor(frame_id):
+        # host-side frame index: the reference's `mat[frame_id]` raises IndexError outside [-capacity, capacity) -- so does this.
+        # (A device-side index cannot be checked without a synchronisation: the kernel then poisons the composed weights with NaN.)
+        f = int(frame_id)
+        for l in res:
+            cap = int(l.weights_t.shape[0])
+            if not -cap <= f < cap:
+                raise IndexError(f"frame_id {f} is out of range for a ResField layer with capacity {cap} (n_frames)")
+        frame_id = f % int(res[0].weights_t.shape[0]) if f < 0 else f
     frame = frame_id if torch.is_tensor(frame_id) else torch.tensor(int(frame_id), dtype=torch.int64, device=res[0].weight.device)
     flat = []
     for l in res:

@@ -211,3 +211,38 @@ def test_model_wrapper_optimizer_schedule_and_checkpoints(tmp_path):
     assert torch.equal(next(model.deform.parameters()), saved)
     model.load_weights(str(tmp_path))                               # latest = 12
     assert torch.equal(next(model.deform.parameters()), saved + 1.0)
+
+
+def test_reference_generator_checkpoint_is_refused_loudly():
+    """A reference DEFAULT-config `deform.pth` carries the weights of its time-conditioned plane generators (`encoder.subs.*`,
+    reference scene/tripFields.py:383-428).  The decoder-free sampler built here has no place for them: loading must say so
+    instead of failing on a key listing (or, non-strict, silently training free planes); unknown encoder_args are reported."""
+    import warnings
+    from splatfields_amd.deform_field import SplatFields
+    net = SplatFields(n_frames=0, encoder_args={"noise_res": 1})
+    state = {k: v.clone() for k, v in net.state_dict().items() if k != "encoder.planes"}
+    state["encoder.subs.0.net.decoder.conv_in.weight"] = torch.zeros(4, 4, 3, 3)
+    with pytest.raises(RuntimeError, match="GENERATOR"):
+        net.load_state_dict(state)
+    with pytest.raises(RuntimeError, match="GENERATOR"):
+        net.load_state_dict(state, strict=False)
+    net.load_state_dict(net.state_dict())                      # its own checkpoints still load
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        SplatFields(n_frames=0, encoder_args={"noise_res": 1, "layer_kwargs": {"x": 1}, "contract_ngp": True})
+    assert any("contract_ngp" in str(x.message) and "layer_kwargs" in str(x.message) for x in w)
+
+
+def test_resfield_frame_index_is_bounds_checked_on_the_host():
+    """reference utils/resfields.py: `mat[frame_id]` raises IndexError outside the capacity; so does a host-side frame index here
+    (a device-side one cannot be checked without a synchronisation: the kernel poisons the composed weights with NaN instead)."""
+    from splatfields_amd.general_mlp import GeneralMLP, compose_resfield_weights
+    mlp = GeneralMLP(in_features=3, out_features=3, hidden_features=16, num_hidden_layers=3, skips=(), multires=0, act="leaky_relu",
+                     composition_rank=2, n_frames=5)
+    layers = list(mlp.net)
+    assert any(l.has_residual for l in layers)
+    compose_resfield_weights(layers, 4)
+    compose_resfield_weights(layers, -1)
+    for bad in (5, -6, 100):
+        with pytest.raises(IndexError):
+            compose_resfield_weights(layers, bad)
