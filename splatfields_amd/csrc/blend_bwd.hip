@@ -154,7 +154,8 @@ __device__ __forceinline__ uint32_t row_scan_add_u32(uint32_t x) {
 struct BwdEntry {
     int pos;            // list position (descending with the thread index), < 0: none
     float2 c;           // splat centre in pixels
-    float4 r1, r2;      // record quarters (p, s, q, -log2 o) (r, g, b, depth)
+    float2 ef;          // (E0, F0): the per-(tile, entry) part of the exponent (common.h: exponent_terms)
+    float4 r1, r2;      // record quarters (p, p s [s in the record], q, -log2 o) (r, g, b, depth)
     uint32_t qm;        // quad-reach mask the forward computed for this (tile, entry)
     uint32_t inst;      // instance index of the (splat, tile) pair: slot of the gradient scratch
 };
@@ -169,6 +170,12 @@ __device__ __forceinline__ BwdEntry load_entry(const Geom& g, const uint32_t* id
     e.pos = pos;
     e.c = *reinterpret_cast<const float2*>(rec);
     e.r1 = rec[1]; e.r2 = rec[2];
+    {   // what the forward's staging thread did with the same record (render.hip): same function, same inputs, same bits
+        float E0, F0, ps;
+        exponent_terms(e.c.x, e.c.y, e.r1, (float)(tx * kTile), (float)(ty * kTile), E0, F0, ps);
+        e.ef = make_float2(E0, F0);
+        e.r1.y = ps;
+    }
     const float4 r3 = rec[3];   // (tile rect origin, rect width, first instance relative to the splat's 256-splat sub-batch): the
                                 // instance index = the splat's first instance + the tile's row-major position in its rect
     const uint32_t rect_xy = __float_as_uint(r3.x), rect_w = __float_as_uint(r3.y);
@@ -181,23 +188,23 @@ __device__ __forceinline__ BwdEntry load_entry(const Geom& g, const uint32_t* id
 
 // ---- the LDS slot of one (quad, entry) pair -------------------------------------------------------------------------
 // It first carries the entry's record to the wavefront that replays the quad, then the ten sums back to the entry's thread:
-//   in : [0] cx  [1] cy  [2] list position (int bits)  [3] p | [4] s  [5] q  [6] -log2 o  [7] r | [8] g  [9] b | ([10] depth)
+//   in : [0] E0  [1] F0  [2] list position (int bits)  [3] p | [4] p s  [5] q  [6] -log2 o  [7] r | [8] g  [9] b | ([10] depth)
 //   out: [0..3] M0 MX MY MXX | [4..7] MXY MYY dr dg | [8] db  [9] d(depth)
 // 10 floats (8-byte aligned, moved as 64-bit pieces) unless the depth gradient is live: then 12 floats, 128-bit pieces.
 template <bool HAS_D> struct SlotFmt { static constexpr int kF = HAS_D ? 12 : 10; };
 
-struct SlotIn { float cx, cy, p, s, q, nlo, r, g, b, depth; int pos; };
+struct SlotIn { float E0, F0, p, ps, q, nlo, r, g, b, depth; int pos; };
 
 template <bool HAS_D>
 __device__ __forceinline__ void slot_put_record(float* sl, const BwdEntry& e) {
     if constexpr (HAS_D) {
         float4* d = reinterpret_cast<float4*>(sl);
-        d[0] = make_float4(e.c.x, e.c.y, __int_as_float(e.pos), e.r1.x);
+        d[0] = make_float4(e.ef.x, e.ef.y, __int_as_float(e.pos), e.r1.x);
         d[1] = make_float4(e.r1.y, e.r1.z, e.r1.w, e.r2.x);
         d[2] = make_float4(e.r2.y, e.r2.z, e.r2.w, 0.f);
     } else {
         float2* d = reinterpret_cast<float2*>(sl);
-        d[0] = make_float2(e.c.x, e.c.y);
+        d[0] = make_float2(e.ef.x, e.ef.y);
         d[1] = make_float2(__int_as_float(e.pos), e.r1.x);
         d[2] = make_float2(e.r1.y, e.r1.z);
         d[3] = make_float2(e.r1.w, e.r2.x);
@@ -210,14 +217,14 @@ __device__ __forceinline__ SlotIn slot_get_record(const float* sl) {
     if constexpr (HAS_D) {
         const float4* d = reinterpret_cast<const float4*>(sl);
         const float4 a = d[0], b = d[1], c = d[2];
-        r.cx = a.x; r.cy = a.y; r.pos = __float_as_int(a.z); r.p = a.w;
-        r.s = b.x; r.q = b.y; r.nlo = b.z; r.r = b.w;
+        r.E0 = a.x; r.F0 = a.y; r.pos = __float_as_int(a.z); r.p = a.w;
+        r.ps = b.x; r.q = b.y; r.nlo = b.z; r.r = b.w;
         r.g = c.x; r.b = c.y; r.depth = c.z;
     } else {
         const float2* d = reinterpret_cast<const float2*>(sl);
         const float2 a = d[0], b = d[1], c = d[2], e = d[3], f = d[4];
-        r.cx = a.x; r.cy = a.y; r.pos = __float_as_int(b.x); r.p = b.y;
-        r.s = c.x; r.q = c.y; r.nlo = e.x; r.r = e.y;
+        r.E0 = a.x; r.F0 = a.y; r.pos = __float_as_int(b.x); r.p = b.y;
+        r.ps = c.x; r.q = c.y; r.nlo = e.x; r.r = e.y;
         r.g = f.x; r.b = f.y; r.depth = 0.f;
     }
     return r;
@@ -226,8 +233,8 @@ __device__ __forceinline__ SlotIn slot_get_record(const float* sl) {
 __device__ __forceinline__ void slot_mask_invalid(SlotIn& r, bool valid) {
     r.nlo = valid ? r.nlo : __builtin_inff();
     r.pos = valid ? r.pos : 0x7fffffff;
-    r.cx = valid ? r.cx : 0.f; r.cy = valid ? r.cy : 0.f;
-    r.p = valid ? r.p : 0.f; r.s = valid ? r.s : 0.f; r.q = valid ? r.q : 0.f;
+    r.E0 = valid ? r.E0 : 0.f; r.F0 = valid ? r.F0 : 0.f;
+    r.p = valid ? r.p : 0.f; r.ps = valid ? r.ps : 0.f; r.q = valid ? r.q : 0.f;
     r.r = valid ? r.r : 0.f; r.g = valid ? r.g : 0.f; r.b = valid ? r.b : 0.f; r.depth = valid ? r.depth : 0.f;
 }
 // rows 4 k .. 4 k + 3 of the 16 x 16 result (k = lane >> 4 < 3) -> floats [4 k, 4 k + 3] of the slot
@@ -255,9 +262,9 @@ __device__ __forceinline__ void slot_get_sums(const float* sl, float4& a, float4
 
 // Per-quad constants of the replay (pixel row k of the quad, pixel columns t = 0..3).
 struct QuadCtx {
-    float pxf[4], gR[4], gG[4], gB[4], gD[4], gA[4], A1[4], A2[4];
+    float gR[4], gG[4], gB[4], gD[4], gA[4], A1[4], A2[4];
     int last[4];
-    float pyf;
+    float X0, Y;   // tile-relative pixel coordinates: column t of the quad is X0 + t, this lane's row is Y
 };
 
 // One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
@@ -308,16 +315,16 @@ template <bool UP> __device__ __forceinline__ void row_scan_add4(float (&x)[4]) 
 
 template <bool UP, bool HAS_D>
 __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e, float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
-    const float dy = e.cy - c.pyf;
-    const float4 f = make_float4(e.p, e.s, e.q, e.nlo);
     float oG[4], oGc[4], alpha[4], ginv[4], x[4], T[4], wgt[4], cgv[4], z[4], y[4];
-    // opacity * G of the four pixels of this row: the forward's instruction sequence (pair_alpha_unclamped), so both passes
-    // make the same alpha >= 1/255 decisions
+    // opacity * G of the four pixels of this row: the forward's expression (common.h: pair_alpha_row / pair_alpha_px), so both
+    // passes make the same alpha >= 1/255 decisions; the row part is shared by the four columns
+    float G0, K;
+    pair_alpha_row(c.Y, e.E0, e.F0, e.ps, e.q, e.nlo, G0, K);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_unclamped(e.cx - c.pxf[t], dy, f);
+    for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_px(c.X0 + (float)t, e.p, G0, K);
 #if SR_BWD_DIAG & 64
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const float tt = f.x * fmaf(f.y, dy, e.cx - c.pxf[t]); oG[t] = fmaf(tt, tt, f.w) * 0.001f; }   // timing experiment: no v_exp
+    for (int t = 0; t < 4; ++t) { const float tt = fmaf(-e.p, c.X0 + (float)t, G0); oG[t] = fmaf(tt, tt, K) * 0.001f; }   // timing experiment: no v_exp
 #endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -579,7 +586,8 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
                 QuadCtx c;
                 float ST[4], SB[4];
-                c.pyf = ty0f + (float)(4 * qy + k);
+                c.Y = (float)(4 * qy + k);
+                c.X0 = (float)(4 * qx);
                 const float Y = (float)(4 * qy + k) - 7.5f;
                 // MFMA A operands: this lane supplies row m = lane & 15 of the 16 x 4 operand for pixel row k.
                 // rows 0-5: pixel monomials 1, X, Y, X^2, XY, Y^2 = c0 + X (c1 + X c2); rows 6-9: dL/d(r, g, b, depth)
@@ -592,7 +600,6 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                     const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
                     c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
                     c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
-                    c.pxf[t] = tx0f + (float)(4 * qx + t);
                     const float X = (float)(4 * qx + t) - 7.5f;
                     c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
                     c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));

@@ -310,6 +310,31 @@ __device__ __forceinline__ float pair_alpha_unclamped(float dx, float dy, const 
     const float w = fmaf(u, u, fmaf(t, t, f.w));
     return __builtin_amdgcn_exp2f(-w);   // = opacity * G
 }
+// The same exponent in TILE-relative coordinates, split into a per-(tile, entry) part -- computed once by the thread that stages
+// the entry -- and a per-pixel part:
+//   t = p (dx + s dy) = E0 - p X - (p s) Y,   u = q dy = F0 - q Y,      E0 = p (cx' + s cy'),  F0 = q cy',
+// with (cx', cy') the splat centre and (X, Y) the pixel, both relative to the tile's first pixel (|cx'|, |cy'| <= support radius
+// + 16, X, Y in 0..15: everything of order one, no cancellation of image-sized coordinates).  Per pair: 5 multiply-adds
+// and one v_exp_f32 instead of 7 + v_exp_f32 in the forward blend, and 2 + v_exp_f32 per pixel column in the entry-per-lane
+// backward, where the Y terms are per bucket (forward -6 %, backward replay -8 % VALU instructions).  Forward and backward
+// evaluate the SAME expression tree on the same inputs (both through these two functions), so they make the same
+// alpha >= 1/255 decisions bit for bit.
+__device__ __forceinline__ void exponent_terms(float cx, float cy, const float4 f, float tx0f, float ty0f, float& E0, float& F0, float& ps) {
+    const float cxr = cx - tx0f, cyr = cy - ty0f;
+    E0 = f.x * fmaf(f.y, cyr, cxr);
+    F0 = f.z * cyr;
+    ps = f.x * f.y;
+}
+// row part (shared by the pixels of a row): G0 = E0 - ps Y,  K = (F0 - q Y)^2 + nlo;   pixel: opacity * G = exp2(-((G0 - p X)^2 + K))
+__device__ __forceinline__ void pair_alpha_row(float Y, float E0, float F0, float ps, float q, float nlo, float& G0, float& K) {
+    G0 = fmaf(-ps, Y, E0);
+    const float L2 = fmaf(-q, Y, F0);
+    K = fmaf(L2, L2, nlo);
+}
+__device__ __forceinline__ float pair_alpha_px(float X, float p, float G0, float K) {
+    const float L1 = fmaf(-p, X, G0);
+    return __builtin_amdgcn_exp2f(-fmaf(L1, L1, K));   // = opacity * G
+}
 // Q' = conic * log2(e) back from the factors (the support test works on the quadratic form)
 // (The tile-reach decision built on this -- tile_test_prepare / tile_reached / edge_min -- is evaluated by k_count_tiles and
 // again by k_emit, and the two MUST agree bit for bit, or a chunk's piece of a tile segment overflows into its neighbour's:

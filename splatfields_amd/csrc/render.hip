@@ -106,9 +106,8 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
     const bool inside = px < v.W && py < v.H;
-    const float pxf = (float)px, pyf = (float)py;
     const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
-    const float sxf = (float)sx, syf = (float)sy; (void)sxf; (void)syf;
+    const float Xf = (float)(px - tx * kTile), Yf = (float)(py - ty * kTile);   // this lane's pixel relative to the tile
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
     // the four 4x4 quads of this wavefront's 8x8 sub-tile as bits 4 qy + qx
     const uint32_t my_quads = 0x33u << (2 * (wave & 1) + 8 * (wave >> 1));
@@ -149,6 +148,12 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             const float4 r0 = s_r0[buf][slot], r1 = s_r1[buf][slot];
             qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
             b.qmask[i] = qm;
+            // the per-(tile, entry) part of the exponent (common.h: exponent_terms) replaces the centre and the factor s in
+            // the staged record: the blend loop needs neither any more
+            float E0, F0, ps;
+            exponent_terms(r0.x, r0.y, r1, tx0f, ty0f, E0, F0, ps);
+            *reinterpret_cast<float2*>(&s_r0[buf][slot]) = make_float2(E0, F0);
+            s_r1[buf][slot].y = ps;
         }
 #endif
         s_qm[buf][slot] = (uint16_t)qm;
@@ -190,23 +195,25 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             // (The loop is co-limited by the scalar unit: ~4.3 cycles per SALU instruction per SIMD on MI355X.)
             for (int c = 0; c < cnt; c += kWave) {
                 const int el = c + lane;
-#ifdef SR_FWD_SUBTILE_TEST
-                const int ec = el < cnt ? el : cnt - 1;
-                const bool ok = el < cnt && subtile_overlap(s_r0[buf][ec], s_r1[buf][ec], sxf, syf);
-#else
                 const bool ok = el < cnt && ((uint32_t)s_qm[buf][el < cnt ? el : 0] & my_quads) != 0u;
-#endif
                 uint64_t m = __builtin_amdgcn_ballot_w64(ok);
 #if defined(SR_FWD_DIAG) && (SR_FWD_DIAG & 1)
                 m = 0ull;   // timing experiment: staging, masks and barriers only
 #endif
                 const uint32_t pos0 = (base - start) + (uint32_t)c;
+                // (Two list entries per trip -- their six LDS reads issued together, the two exponent chains independent, the odd
+                // entry masked on the scalar unit -- was built in round 4: 0.1206 vs 0.1120 ms, SLOWER: the pairing costs more
+                // scalar instructions (two s_ff1, selects, a branch for the odd entry) than the shared latency gives back; with
+                // eight wavefronts per SIMD the other wavefronts already cover one entry's LDS round trip.)
                 while (m) {
                     const int bit = (int)__builtin_ctzll(m);
                     m &= ~(1ull << bit);
                     const int e = c + bit;
-                    const float4 r0 = s_r0[buf][e], r1 = s_r1[buf][e], r2 = s_r2[buf][e];
-                    const float alpha = fminf(kAlphaMax, pair_alpha_unclamped(r0.x - pxf, r0.y - pyf, r1));
+                    const float2 ef = *reinterpret_cast<const float2*>(&s_r0[buf][e]);   // (E0, F0)
+                    const float4 r1 = s_r1[buf][e], r2 = s_r2[buf][e];                     // (p, p s, q, -log2 o), (r, g, b, depth)
+                    float G0, K;
+                    pair_alpha_row(Yf, ef.x, ef.y, r1.y, r1.z, r1.w, G0, K);
+                    const float alpha = fminf(kAlphaMax, pair_alpha_px(Xf, r1.x, G0, K));
                     const float test_T = T * (1.0f - alpha);
                     const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & livem;
                     const uint64_t stopm = __builtin_amdgcn_ballot_w64(test_T < kTStop) & hitm;
@@ -256,6 +263,8 @@ done:
 void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                            float* out_color, float* out_depth, float* out_alpha, hipStream_t st) {
     const int tiles = v.gx * v.gy;
+    // (Occupancy: eight workgroups per CU.  Capping it with LDS padding was measured in round 4 -- 7 / 6 / 5 per CU: 0.1235 /
+    // 0.130 / 0.1525 ms against 0.114 -- the kernel lives on its eight wavefronts per SIMD; the 1.22-round tail is not the cost.)
     if (tiles > 0) hipLaunchKernelGGL(k_render_forward, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, out_color, out_depth, out_alpha);
 }
 
@@ -276,6 +285,8 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     __shared__ float4 s_r1[kBwdBatch + 1];
     __shared__ float4 s_r2[kBwdBatch + 1];
     __shared__ float4 s_acc[4][kBwdBatch][3];
+    __shared__ float2 s_ef[kBwdBatch + 1];   // (E0, F0): the per-(tile, entry) part of the exponent (common.h: exponent_terms);
+                                             // p s rides in the unused fourth component of s_r0
     __shared__ uint32_t s_max[4];
 
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
@@ -285,6 +296,8 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
     const int px = sx + (lane & 7), py = sy + (lane >> 3);
     const bool inside = px < v.W && py < v.H;
     const float pxf = (float)px, pyf = (float)py, sxf = (float)sx, syf = (float)sy;
+    const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
+    const float Xf = (float)(px - tx * kTile), Yf = (float)(py - ty * kTile);
     const uint32_t start = g.tile_start[tile], end = g.tile_start[tile + 1];
     const int n = (int)(end - start);
     const size_t hw = (size_t)v.H * v.W, pix = (size_t)py * v.W + px;
@@ -316,6 +329,7 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
         s_r0[kBwdBatch] = zero4;
         s_r1[kBwdBatch] = make_float4(0.f, 0.f, 0.f, __builtin_inff());
         s_r2[kBwdBatch] = zero4;
+        s_ef[kBwdBatch] = make_float2(0.f, 0.f);
     }
     float T = T_final;
     float behind_g = T_final * bg_dot;  // (colour accumulated behind the current splat, incl. background) . upstream gradient
@@ -332,9 +346,12 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
             const float4* rec = g.rec + 4 * (size_t)id;
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
             const uint32_t inst_first = g.block_offsets[id >> 8] + __float_as_uint(r3.z);   // see load_entry (blend_bwd.hip)
-            s_r0[threadIdx.x] = r0;
+            float E0, F0, ps;
+            exponent_terms(r0.x, r0.y, r1, tx0f, ty0f, E0, F0, ps);
+            s_r0[threadIdx.x] = make_float4(r0.x, r0.y, r0.z, ps);
             s_r1[threadIdx.x] = r1;
             s_r2[threadIdx.x] = r2;
+            s_ef[threadIdx.x] = make_float2(E0, F0);
             const uint32_t xy = __float_as_uint(r3.x), rw = __float_as_uint(r3.y);
             inst_v = inst_first + ((uint32_t)ty - (xy >> 16)) * rw + ((uint32_t)tx - (xy & 0xffffu));
         }
@@ -364,7 +381,10 @@ __global__ void __launch_bounds__(kBlock) k_render_backward(const ViewK v, const
                         ent[q] = e;
                         const float4 r0 = s_r0[e], r1 = s_r1[e], r2 = s_r2[e];
                         const float dx = r0.x - pxf, dy = r0.y - pyf;
-                        const float oG = pair_alpha_unclamped(dx, dy, r1);   // opacity * G, same sequence as the forward
+                        const float2 ef = s_ef[e];
+                        float G0, K;
+                        pair_alpha_row(Yf, ef.x, ef.y, r0.w, r1.z, r1.w, G0, K);
+                        const float oG = pair_alpha_px(Xf, r1.x, G0, K);   // opacity * G, the forward's expression
                         // Who contributes is decided on the scalar unit (oG >= 1/255 is the forward's alpha >= 1/255: the
                         // 0.99 clamp does not move that threshold).  Everyone else gets alpha = G = 0, which makes every
                         // product below 0 and leaves T and behind_g unchanged (1/(1-0) = 1 exactly): no divergent branch, so
