@@ -93,6 +93,40 @@ def pipeline_bytes(n: int, vis: float, R: float, hw: int, c_in: int) -> float:
 
 
 
+# What bounds each stage on MI355X (rocprofv3 SQ counters and the timing experiments of round 4):
+# "hbm" = streams per-splat data at 75-80 % of the achievable bandwidth; "valu" = the two blend kernels (issue + dependent-issue
+# latency of the per-pair arithmetic; their HBM figure is reported because it is the north star's yardstick, not because it
+# bounds them); "latency" = the small dependent kernels of the bucketing chain (launch gaps, LDS atomics, barriers).
+STAGE_BOUND = {"preprocess": "hbm", "preprocess_backward": "hbm", "render_forward": "valu", "render_backward": "valu",
+               "scan": "latency", "emit": "latency", "sort_tiles": "valu"}
+
+
+def roofline_block(stage_ms: dict, n: int, vis: float, R: float, hw: int, c_in: int, ms_per_step: float, ms_median: float,
+                   traffic=None, traffic_why=None, valu=None) -> dict:
+    """The `roofline` object of the JSON line: the dominant stage in the contract's terms (algorithmic bytes per launch / its
+    average duration, against the 8 TB/s HBM peak), what really bounds that stage, and -- the figure the north star is stated in --
+    the whole forward+backward pipeline's algorithmic bytes per step time."""
+    dom = max(stage_ms, key=stage_ms.get)
+    dom_bytes = stage_bytes(dom, n, vis, R, hw, c_in)
+    dom_bw = dom_bytes / (stage_ms[dom] * 1e-3)
+    b_alg = pipeline_bytes(n, vis, R, hw, c_in)
+    out = {"bound": STAGE_BOUND[dom], "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+           "frac": dom_bw / HBM_PEAK, "frac_basis": "algorithmic bytes per launch / average launch duration / 8 TB/s HBM peak",
+           "traffic": traffic, "traffic_note": traffic_why, "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dom],
+           "stage_bound": {k: STAGE_BOUND[k] for k in stage_ms},
+           "pipeline_b_alg_bytes": b_alg, "pipeline_achieved": b_alg / (ms_per_step * 1e-3) / 1e9,
+           "pipeline_frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
+           "pipeline_frac_vs_6.29": b_alg / (ms_per_step * 1e-3) / 6.29e12,
+           "pipeline_frac_from_median": b_alg / (ms_median * 1e-3) / HBM_PEAK if ms_median > 0 else None,
+           "note": ("bound = what limits the dominant kernel; the blend kernels are bound by VALU issue and dependent-issue latency, "
+                    "not by HBM: see roofline_valu (SQ counters) and blend_work (pairs evaluated / blended); achieved / frac are "
+                    "the HBM-roofline figures of the task contract; `traffic` is L2<->fabric bytes incl. requests served by the "
+                    "256 MB infinity cache; pipeline_* = SURVEY section 8d's B_alg over the whole fwd+bwd step (north star)")}
+    if valu and valu.get(dom):
+        out["valu_issue_frac"] = valu[dom].get("valu_issue_frac")
+    return out
+
+
 def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, warmup, dev):
     """ms per fwd+bwd step and per-stage HIP-event times of one more single-GPU workload (same step as the headline)."""
     import math
@@ -127,11 +161,18 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
+    # same estimators as the headline: wall-clock mean of the K steps (ms_per_step) and the median of per-step HIP-event
+    # times (ms_per_step_median: one host stall -- the allocator, a subprocess that just ran -- does not become the figure)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    stream = torch.cuda.current_stream(dev)
     t0 = time.perf_counter()
     for i in range(steps):
+        marks[i].record(stream)
         step(warmup + i)
+    marks[steps].record(stream)
     torch.cuda.synchronize()
     ms_per_step = (time.perf_counter() - t0) / steps * 1e3
+    ms_median = median([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)])
     lib.sr_profile_enable(1)
     for i in range(steps):
         step(warmup + i, record=(i == steps - 1))
@@ -148,10 +189,12 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
     blend = stage_ms["render_forward"] + stage_ms["render_backward"]
     return {"splats": n, "width": width, "height": height, "mean_scale": mean_scale,
             "color": "sh%d" % sh_degree if use_sh else "precomp", "steps": steps, "ms_per_step": ms_per_step,
+            "ms_per_step_median": ms_median, "stage_ms_sum": sum(stage_ms.values()),
             "value": n * height * width / (ms_per_step * 1e-3), "tile_instances": R, "instances_per_splat": R / n,
             "visible_splats": vis[0], "stage_ms": stage_ms, "binning_over_blend": binning / blend if blend > 0 else None,
             "sort_keys_per_s": R / (stage_ms["sort_tiles"] * 1e-3) if stage_ms["sort_tiles"] > 0 else None,
-            "roofline_pipeline_frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK}
+            "roofline_pipeline_frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
+            "roofline_pipeline_frac_from_median": b_alg / (ms_median * 1e-3) / HBM_PEAK if ms_median > 0 else None}
 
 
 def blend_work_counters(n, width, height, mean_scale):
@@ -421,8 +464,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(med, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ms_wall = elapsed / args.steps * 1e3
-    ms_per_step = float(med.item())
+    # `ms_per_step` = wall clock of the K timed steps / K -- the estimator `value` uses and the task contract names; the median
+    # of the per-step HIP-event times rides beside it (ms_per_step_median: robust against one slow step)
+    ms_per_step = elapsed / args.steps * 1e3
+    ms_median = float(med.item())
     value = world * N * H * W * args.steps / elapsed
     exchange = ExchangeStats.summary() if ExchangeStats.enabled else None
     ExchangeStats.reset(False)
@@ -431,7 +476,7 @@ def main():
         if rank == 0:
             print(f"[bench] {msg} (+{time.perf_counter() - t_start:.1f} s)", file=sys.stderr, flush=True)
 
-    progress(f"timed {args.steps} steps: median {ms_per_step:.4f} ms/step, wall-clock mean {ms_wall:.4f}")
+    progress(f"timed {args.steps} steps: wall-clock mean {ms_per_step:.4f} ms/step, median {ms_median:.4f}")
     # ---- per-stage durations with HIP events on the launch stream (same steps, same inputs) ----
     lib.sr_profile_enable(1)
     for i in range(args.steps):
@@ -444,20 +489,19 @@ def main():
     stage_ms = {lib.sr_profile_stage_name(i).decode(): (ms[i] / max(cnt[i], 1)) for i in range(_lib.PROFILE_STAGES)}
     R = stats["R"] / max(stats["n"], 1)
     vis = stats["vis"] / max(stats["n"], 1)
-    dom = max(stage_ms, key=stage_ms.get)
-    dom_bytes = stage_bytes(dom, N, vis, R, H * W, c_in)
-    dom_bw = dom_bytes / (stage_ms[dom] * 1e-3)
     b_alg = pipeline_bytes(N, vis, R, H * W, c_in)
     wl = {"splats": N, "width": W, "height": H, "color": args.color, "sh_degree": args.sh_degree, "mean_scale": args.mean_scale}
     tj, traffic_why = recorded_counters("traffic.json", wl)   # PMC bytes of this workload and these kernel sources only
+    dom = max(stage_ms, key=stage_ms.get)
     traffic = tj.get(dom) if tj else None
 
     out = {
         "metric": "splats*px rasterized/sec (fwd+bwd)", "value": value, "unit": "splat*px/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_wall_mean": ms_wall,
-        "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_step_median": ms_median,
+        "ms_per_step_wall_mean": ms_per_step, "ms_per_step_min": min(step_ms), "ms_per_step_max": max(step_ms),
         "timing": "value = work / wall-clock of the K timed steps (barrier + synchronize on both sides, max over ranks); ms_per_step = "
-                  "median over the K per-step HIP-event times (max over ranks), ms_per_step_wall_mean = that wall-clock / K",
+                  "that wall-clock / K (= ms_per_step_wall_mean); ms_per_step_median / _min / _max = per-step HIP-event times "
+                  "on the launch stream (max over ranks)",
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
@@ -468,26 +512,16 @@ def main():
                                    "allreduce": ", RCCL sum all-reduce of per-splat gradients"}[state["mode"]] if world > 1 else ""),
                    "splats": N, "width": W, "height": H, "views_per_step": world,
                    "visible_splats": vis, "tile_instances": R, "inputs": args.inputs, "dp_mode": state["mode"] if (world > 1 or args.force_dp_path) else None},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bw / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": dom_bw / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_why,
-                     "algorithmic_bytes_per_launch": dom_bytes,
-                     "avg_launch_ms": stage_ms[dom],
-                     "note": ("the two blend kernels are VALU-issue-bound, not HBM-bound (rocprofv3 SQ counters in profiles/: 4.6-4.9 "
-                              "launch cycles per wave-level VALU instruction per SIMD); `traffic` is L2<->fabric bytes incl. requests "
-                              "served by the 256 MB infinity cache; the HBM-bound stages are preprocess / preprocess_backward "
-                              "(DESIGN.md section 5)")},
+        "roofline": roofline_block(stage_ms, N, vis, R, H * W, c_in, ms_per_step, ms_median, traffic, traffic_why),
         "roofline_pipeline": {"b_alg_bytes": b_alg, "achieved": b_alg / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                               "frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
-                              "frac_from_wall_mean": b_alg / (ms_wall * 1e-3) / HBM_PEAK,
+                              "frac_from_median": b_alg / (ms_median * 1e-3) / HBM_PEAK,
                               "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
-        "stage_ms": stage_ms,
+        "stage_ms": stage_ms, "stage_ms_sum": sum(stage_ms.values()),
         # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
         "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }
     progress("stage pass done")
-    out["roofline"]["note"] = ("the blend kernels are VALU-issue-bound, not HBM-bound: see roofline_valu (SQ counters) and blend_work "
-                               "(pairs evaluated / blended); `traffic` is L2<->fabric bytes incl. requests served by the 256 MB "
-                               "infinity cache; the HBM-bound stages are preprocess / preprocess_backward (DESIGN.md section 5)")
     pairs_blended = None
     if rank == 0 and world == 1 and args.extra_workloads != "none":
         try:
@@ -497,6 +531,8 @@ def main():
             out["blend_work"] = {"error": repr(e)}
         progress("blend_work done")
     out["roofline_valu"] = valu_roofline(wl, stage_ms, pairs_blended)
+    if out["roofline_valu"] and out["roofline_valu"].get(dom):
+        out["roofline"]["valu_issue_frac"] = out["roofline_valu"][dom].get("valu_issue_frac")
     if world > 1 or args.force_dp_path:
         # what a first run on a multi-GPU node needs to be diagnosed: which scheme ran over how many RCCL ranks, how long the
         # exchange window of a step is, how much of it is covered by local compute, what every GPU puts on the wire
@@ -505,7 +541,7 @@ def main():
             "dp_mode": state["mode"], "backend": args.backend if world > 1 else None,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "exchange_ms": ex.get("exchange_ms"), "overlap_ms": ex.get("overlap_ms"),
-            "compute_ms": (ms_per_step - ex["exchange_ms"] + ex["overlap_ms"]) if ex else None,
+            "compute_ms": (ms_median - ex["exchange_ms"] + ex["overlap_ms"]) if ex else None,
             "exposed_exchange_ms": (ex["exchange_ms"] - ex["overlap_ms"]) if ex else None,
             "wire_bytes_per_gpu": ex.get("wire_bytes_per_gpu"),
             "wire_bytes_per_splat_per_gpu": (ex["wire_bytes_per_gpu"] / N) if ex else None,
@@ -518,7 +554,10 @@ def main():
                  ("dense: 300 k splats, mean scale 0.02", 300_000, 800, 800, True, 0.02),
                  ("dense: 100 k splats, mean scale 0.05", 100_000, 800, 800, True, 0.05)]
         out["other_workloads"] = []
+        del params, sp     # the headline's tensors: every side workload starts from a drained device and an empty allocator cache
         for name, n_, w_, h_, sh_, ms_ in extra:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             r = time_plain_workload(n_, w_, h_, sh_, ms_, args.sh_degree, 20, 8, dev)
             r["name"] = name
             out["other_workloads"].append(r)

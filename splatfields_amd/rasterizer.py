@@ -75,6 +75,10 @@ def set_backward_kernel(which) -> str:
 _CAPACITY = {}
 _INSTANCES_PER_SPLAT = {}
 _CAPACITY_HEADROOM = 1.25
+# The library takes concurrent calls from host threads that render on their own streams (include/splatraster.h); these two
+# module-level estimates are the only state the facade shares between them: updated under a lock (read-modify-write of a max).
+import threading
+_CAPACITY_LOCK = threading.Lock()
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -229,9 +233,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             # known size: what it needed before; new size (the cloud was densified / pruned): the instances-per-splat ratio
             # this image size has shown so far, so that the first forward after a densification step does not fall into the
             # re-run path
-            ratio = _INSTANCES_PER_SPLAT.get((dev.index, H, W))
-            capacity = _CAPACITY.get(key) or (max(4 * n, 1 << 16) if ratio is None
-                                              else int(ratio * n * _CAPACITY_HEADROOM) + 1024)
+            with _CAPACITY_LOCK:
+                ratio = _INSTANCES_PER_SPLAT.get((dev.index, H, W))
+                capacity = _CAPACITY.get(key) or (max(4 * n, 1 << 16) if ratio is None
+                                                  else int(ratio * n * _CAPACITY_HEADROOM) + 1024)
             binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
             status = lib.sr_forward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
                                     capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), C.byref(inst), stream)
@@ -244,11 +249,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                  capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), stream))
             else:
                 _lib.check(status)
-            _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(instances * _CAPACITY_HEADROOM) + 1024)
-            if len(_CAPACITY) > 4096:  # a long training run changes the splat count thousands of times
-                _CAPACITY.clear()
-            rkey = (dev.index, H, W)
-            _INSTANCES_PER_SPLAT[rkey] = max(_INSTANCES_PER_SPLAT.get(rkey, 0.0), instances / max(n, 1))
+            with _CAPACITY_LOCK:
+                _CAPACITY[key] = max(_CAPACITY.get(key, 0), int(instances * _CAPACITY_HEADROOM) + 1024)
+                if len(_CAPACITY) > 4096:  # a long training run changes the splat count thousands of times
+                    _CAPACITY.clear()
+                rkey = (dev.index, H, W)
+                _INSTANCES_PER_SPLAT[rkey] = max(_INSTANCES_PER_SPLAT.get(rkey, 0.0), instances / max(n, 1))
         global LAST_INSTANCES
         LAST_INSTANCES = instances
         ctx.instances = instances

@@ -27,6 +27,27 @@ def test_stage_bytes_are_positive_and_scale_with_their_units():
     assert bench.stage_bytes("render_forward", 0, 0, 0, 10, 12) == 280
 
 
+def test_roofline_block_carries_the_pipeline_figure_and_the_real_bound():
+    """`roofline` (the object the driver records): dominant stage in HBM terms as the contract defines it, what bounds that stage,
+    and the north star's pipeline figure B_alg / ms_per_step inside the same object."""
+    stage_ms = {"preprocess": 0.07, "scan": 0.05, "emit": 0.03, "sort_tiles": 0.04, "render_forward": 0.11, "render_backward": 0.24,
+                "preprocess_backward": 0.09}
+    n, vis, R, hw, c_in = 1_000_000, 960_000.0, 2_290_000.0, 640_000, 192
+    rf = bench.roofline_block(stage_ms, n, vis, R, hw, c_in, ms_per_step=0.64, ms_median=0.63, traffic=5.0e8, traffic_why=None,
+                              valu={"render_backward": {"valu_issue_frac": 0.3}})
+    assert rf["kernel"] == "render_backward" and rf["bound"] == "valu" and rf["valu_issue_frac"] == 0.3 and rf["traffic"] == 5.0e8
+    want = bench.stage_bytes("render_backward", n, vis, R, hw, c_in) / 0.24e-3
+    assert abs(rf["achieved"] - want / 1e9) < 1e-9 and abs(rf["frac"] - want / 8e12) < 1e-12 and rf["peak"] == 8000.0
+    b_alg = bench.pipeline_bytes(n, vis, R, hw, c_in)
+    assert rf["pipeline_b_alg_bytes"] == b_alg
+    assert abs(rf["pipeline_frac"] - b_alg / 0.64e-3 / 8e12) < 1e-15 and abs(rf["pipeline_frac_vs_6.29"] - b_alg / 0.64e-3 / 6.29e12) < 1e-15
+    assert abs(rf["pipeline_frac_from_median"] - b_alg / 0.63e-3 / 8e12) < 1e-15
+    assert rf["stage_bound"]["preprocess"] == "hbm" and rf["stage_bound"]["emit"] == "latency" and set(rf["stage_bound"]) == set(stage_ms)
+    # an HBM-bound stage dominating (tiny images, huge clouds) is labelled as such
+    rf2 = bench.roofline_block(dict(stage_ms, preprocess_backward=0.5), n, vis, R, hw, c_in, 1.0, 1.0)
+    assert rf2["kernel"] == "preprocess_backward" and rf2["bound"] == "hbm" and "valu_issue_frac" not in rf2
+
+
 def test_roofline_valu_is_reproducible_from_the_committed_counters():
     """bench.py's issue-side roofline comes from profiles/pmc_sq.json (rocprofv3 SQ counter passes): pure arithmetic against
     hardware ceilings (2 cycles per wave-level VALU instruction per SIMD-32, 157.3 TFLOP/s fp32), nothing self-referential."""
