@@ -545,9 +545,23 @@ def main():
             "exposed_exchange_ms": (ex["exchange_ms"] - ex["overlap_ms"]) if ex else None,
             "wire_bytes_per_gpu": ex.get("wire_bytes_per_gpu"),
             "wire_bytes_per_splat_per_gpu": (ex["wire_bytes_per_gpu"] / N) if ex else None,
+            "predicted": None,
             "note": "rank 0's medians over the timed steps; exchange_ms = first collective issued -> last one complete (events on the "
                     "launch stream), overlap_ms = local compute inside that window (the SH-gradient rebuild), wire bytes by the ring "
                     "model (all-reduce 2 (G-1)/G S, all-gather / all-to-all (G-1)/G S)"}
+    if world > 1 or args.force_dp_path:
+        # what this scheme should cost on an 8-GPU node by link arithmetic (view_parallel.predict_scaling), from this run's own
+        # stage times: the first SCALE curve can be checked against it
+        from splatfields_amd import view_parallel as vp
+        single = stage_ms_sum = sum(stage_ms.values())
+        rebuild = (exchange or {}).get("overlap_ms") or 0.09 * (N / 1e6)
+        for gsz in sorted({world, 8} - {1}):
+            pr = vp.predict_scaling(state["mode"], N, gsz, single, tail_ms=stage_ms["preprocess_backward"],
+                                    slices=vp.GATHER_SLICES if state["mode"] == "gather" else 1,
+                                    rebuild_ms=(rebuild * gsz / max(world, 1) if state["mode"] == "gather" else rebuild / gsz if state["mode"] == "shard" else 0.0))
+            pr["compute_ms_source"] = "sum of this run's per-stage HIP-event times (one view, fwd+bwd, no exchange)"
+            out["exchange"].setdefault("predicted_by_world", {})[str(gsz)] = pr
+        out["exchange"]["predicted"] = out["exchange"]["predicted_by_world"].get("8")
     if rank == 0 and world == 1 and args.extra_workloads != "none":
         # SURVEY.md 8d "both colour paths" + denser tile lists (trained scenes sit at 5-15 instances per splat)
         extra = [("headline, precomputed colours", N, W, H, False, args.mean_scale),

@@ -162,6 +162,22 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, vo
                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
                 const SrGrads* grads, void* hip_stream);
 
+/* sr_backward in two calls, for callers that overlap an exchange of finished gradients with the rest of the backward (the
+ * view-parallel training step, splatfields_amd/view_parallel.py; no counterpart in [EXT], which is single-GPU):
+ *   sr_backward_blend   -- the backward blend only: fills `scratch` (one gradient slot per reached tile-splat instance);
+ *   sr_backward_splats  -- the per-splat part (slot reduction + chain rule to means3D / scales / rotations / SH / opacity)
+ *                          for splats [first_splat, first_splat + n_splats) only; first_splat must be a multiple of 256;
+ *                          the SrGrads pointers are the bases of the FULL gradient tensors (rows outside the range are not
+ *                          touched).  Any partition of [0, count) into such ranges, in any order, after one
+ *                          sr_backward_blend, gives exactly what sr_backward gives (same kernels, same arithmetic per splat).
+ * Same buffers and the same `instances` / `instances_rendered` meaning as sr_backward. */
+int sr_backward_blend(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                      long long instances, long long instances_rendered, const void* image,
+                      const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch, void* hip_stream);
+int sr_backward_splats(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                       long long instances, const void* image, const int* radii, void* scratch, const SrGrads* grads,
+                       int first_splat, int n_splats, void* hip_stream);
+
 /* Pins the backward blend kernel for A/B measurements and for the test that compares the two: 0 = chosen per launch by the
  * footprint (default), 1 = pixel-per-lane kernel, 2 = entry-per-lane kernel.  The initial value comes from the environment
  * variable SPLATRASTER_BWD ("wave" = 1, "mfma" = 2), read once when the library is loaded.  Process-wide; returns the

@@ -245,19 +245,26 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, st);
 }
 
-int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
-                long long instances, long long instances_rendered, const void* image, const int* radii,
-                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
-                const SrGrads* grads, void* hip_stream) {
+namespace {
+// what: 1 = backward blend, 2 = per-splat part for splats [first, first + count), 3 = both
+int backward_impl(int what, const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                  long long instances, long long instances_rendered, const void* image, const int* radii,
+                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                  const SrGrads* grads, int first, int count, void* hip_stream) {
     SR_TRY(validate(view, splats));
-    if (!geom || !binning || !image || !dL_dcolor || !scratch || !grads) return fail("null buffer");
-    if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
-    if (splats->count > 0 && splats->shs && !grads->dL_dshs && !grads->dL_dcolors) return fail("dL_dshs (or dL_dcolors for the colour-gradient mode) missing");
-    if (splats->count > 0 && splats->shs_rest && grads->dL_dshs && !grads->dL_dshs_rest) return fail("dL_dshs_rest missing");
-    if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
+    if (!geom || !binning || !image || !scratch) return fail("null buffer");
+    if ((what & 1) && !dL_dcolor) return fail("null buffer");
+    if ((what & 2) && !grads) return fail("null buffer");
+    if (what & 2) {
+        if (splats->count > 0 && (!radii || !grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity)) return fail("null gradient output");
+        if (splats->count > 0 && splats->shs && !grads->dL_dshs && !grads->dL_dcolors) return fail("dL_dshs (or dL_dcolors for the colour-gradient mode) missing");
+        if (splats->count > 0 && splats->shs_rest && grads->dL_dshs && !grads->dL_dshs_rest) return fail("dL_dshs_rest missing");
+        if (splats->count > 0 && splats->colors_precomp && !grads->dL_dcolors) return fail("dL_dcolors missing");
+        if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
+        if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
+        if (first < 0 || count < 0 || (first % sr::kBlock) != 0) return fail("splat range must start at a multiple of 256");
+    }
     if (splats->raw_params & SR_FORWARD_ONLY) return fail("the forward of these buffers was run with SR_FORWARD_ONLY");
-    if (splats->count > 0 && splats->cov3D_precomp && !grads->dL_dcov3D) return fail("dL_dcov3D missing");
-    if (splats->count > 0 && !splats->cov3D_precomp && (!grads->dL_dscales || !grads->dL_drotations)) return fail("dL_dscales/dL_drotations missing");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const sr::ViewK v = make_view(view);
     const sr::SplatsK s = make_splats(splats);
@@ -266,7 +273,7 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, vo
     sr::carve_binning(binning, instances, &b);   // Binning::reached is written by the backward blend (splatraster.h)
     sr::carve_image(const_cast<void*>(image), v.H, v.W, &im);
     float* slots = static_cast<float*>(scratch);
-    {
+    if (what & 1) {
         StageTimer t_(5, st);
         // Two kernels, one slot format.  Entry-per-lane (MFMA moment reduction) wins while a splat reaches few pixels of a tile
         // (measured on MI355X, 800x800: 0.286 vs 0.370 ms at 2.3 instances per splat, 0.207 vs 0.215 at 4.6); pixel-per-lane
@@ -278,17 +285,42 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, vo
         if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
         else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
     }
-    SR_TRY(after_launch(view, st, "render_backward"));
-    sr::GradsK gr;
-    gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
-    gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
-    gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
-    gr.shs = s.shs ? grads->dL_dshs : nullptr;
-    gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
-    gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
-    { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, st); }
-    SR_TRY(after_launch(view, st, "preprocess_backward"));
+    if (what & 1) SR_TRY(after_launch(view, st, "render_backward"));
+    if (what & 2) {
+        sr::GradsK gr;
+        gr.means3D = grads->dL_dmeans3D; gr.means2D = grads->dL_dmeans2D; gr.opacity = grads->dL_dopacity;
+        gr.scales = s.cov3D ? nullptr : grads->dL_dscales; gr.rotations = s.cov3D ? nullptr : grads->dL_drotations;
+        gr.cov3D = s.cov3D ? grads->dL_dcov3D : nullptr;
+        gr.shs = s.shs ? grads->dL_dshs : nullptr;
+        gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
+        gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
+        { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, first, count, st); }
+        SR_TRY(after_launch(view, st, "preprocess_backward"));
+    }
     return 0;
+}
+}  // namespace
+
+int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                long long instances, long long instances_rendered, const void* image, const int* radii,
+                const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                const SrGrads* grads, void* hip_stream) {
+    return backward_impl(3, view, splats, geom, binning, instances, instances_rendered, image, radii, dL_dcolor, dL_ddepth, dL_dalpha,
+                         scratch, grads, 0, splats ? splats->count : 0, hip_stream);
+}
+
+int sr_backward_blend(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                      long long instances, long long instances_rendered, const void* image,
+                      const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch, void* hip_stream) {
+    return backward_impl(1, view, splats, geom, binning, instances, instances_rendered, image, nullptr, dL_dcolor, dL_ddepth, dL_dalpha,
+                         scratch, nullptr, 0, 0, hip_stream);
+}
+
+int sr_backward_splats(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
+                       long long instances, const void* image, const int* radii, void* scratch, const SrGrads* grads,
+                       int first_splat, int n_splats, void* hip_stream) {
+    return backward_impl(2, view, splats, geom, binning, instances, -1, image, radii, nullptr, nullptr, nullptr, scratch, grads,
+                         first_splat, n_splats, hip_stream);
 }
 
 int sr_set_backward_kernel(int which) {

@@ -384,10 +384,13 @@ template <bool STAGE_SH, bool SH_TO_COLORS>
 __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
                                                                 const int* __restrict__ radii,
                                                                 const float* __restrict__ slots,
-                                                                const uint8_t* __restrict__ reached, const GradsK gr) {
+                                                                const uint8_t* __restrict__ reached, const GradsK gr,
+                                                                const int first_splat, const int end_splat) {
+    // splats [first_splat, end_splat) of the cloud (first_splat a multiple of 256): the whole cloud in one launch, or one
+    // slice of it per launch when the caller overlaps an exchange of the finished slices with the rest (sr_backward_splats)
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = idx < s.N;
+    const int idx = first_splat + blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = idx < end_splat;
     int radius_in = 0;
     uint32_t first_in = 0, cnt_in = 0;
     uint8_t flags_in = 0;
@@ -655,22 +658,23 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }  // valid
     if constexpr (STAGE_SH && !SH_TO_COLORS) {
         __syncthreads();
-        const size_t first = (size_t)blockIdx.x * kBlock;
-        if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, s.N - (int)first));
-        else stage_sh_out(s_sh, gr.shs, first, min(kBlock, s.N - (int)first));
+        const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
+        if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
+        else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
     }
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
-                                const float* slots, const uint8_t* reached, const GradsK& gr, hipStream_t st) {
-    const int nb = (s.N + kBlock - 1) / kBlock;
+                                const float* slots, const uint8_t* reached, const GradsK& gr, int first, int count, hipStream_t st) {
+    const int end = first + count < s.N ? first + count : s.N;
+    const int nb = (end - first + kBlock - 1) / kBlock;
     if (nb <= 0) return;
     const bool to_colors = s.shs && !gr.shs && gr.colors;
     const bool stage = s.shs && v.sh_coeffs == 16 && gr.shs;  // LDS rows only carry the SH gradient out (coalesced 16-byte stores)
-    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
-    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
-    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
-    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr);
+    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
+    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
+    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
+    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
 }
 
 }  // namespace sr

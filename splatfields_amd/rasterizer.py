@@ -167,7 +167,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0, sh_rest=None):
+                raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0, sh_rest=None,
+                slice_hook=None):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -204,6 +205,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(n, dtype=torch.int32, device=dev)  # k_preprocess writes every element
         ctx.raster_settings = raster_settings
         ctx.color_grad_sink = color_grad_sink
+        ctx.slice_hook = slice_hook
         # nothing to differentiate (rendering / evaluation under no_grad): the forward skips what only the backward reads
         if not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]):
             raw_params = int(raw_params) | _lib.SR_FORWARD_ONLY
@@ -268,7 +270,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         n = ctx.n
         if n == 0:
-            return (None,) * 12
+            return (None,) * 13
         lib = _lib.load()
         means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image, sh_rest = ctx.saved_tensors
         dev = means3D.device
@@ -280,23 +282,45 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_depth, grad_alpha = g(grad_depth if _DEPTH_GRADIENT else None), g(grad_alpha)
         view = ctx.view_pack  # camera tensors were made contiguous in forward
         new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
-        d_means3D, d_means2D, d_opac = new(n, 3), new(n, 3), new(n, 1)
-        d_sc = new(n, 3) if sc is not None else None
-        d_rot = new(n, 4) if rot is not None else None
-        d_cov = new(n, 6) if cov is not None else None
+        hook = ctx.slice_hook
         sink = ctx.color_grad_sink if sh is not None else None
-        d_sh = new(*sh.shape) if (sh is not None and sink is None) else None
-        d_col = new(n, 3) if (col is not None or sink is not None) else None
-        d_rest = new(*sh_rest.shape) if (sh_rest is not None and d_sh is not None) else None
+        if hook is not None:
+            # sliced mode (view-parallel exchange, splatfields_amd/view_parallel.py): the gradients are written into the HOOK's
+            # buffers, slice by slice, and the hook is called behind every slice's launch -- it starts that slice's collectives
+            # while the next slice is computed.  Autograd gets no gradient for these inputs (the hook's owner sets `.grad`).
+            if cov is not None or sh_rest is not None or (sh is not None and sink is None):
+                raise RuntimeError("slice_hook: scale / rotation inputs, and colour gradients (color_grad_sink) on the SH path")
+            hb = hook.buffers(n)
+            d_means3D, d_sc, d_rot, d_opac, d_col = hb["means3D"], hb["scales"], hb["rotations"], hb["opacities"], hb["colors"]
+            d_means2D, d_cov, d_sh, d_rest = new(n, 3), None, None, None
+        else:
+            d_means3D, d_means2D, d_opac = new(n, 3), new(n, 3), new(n, 1)
+            d_sc = new(n, 3) if sc is not None else None
+            d_rot = new(n, 4) if rot is not None else None
+            d_cov = new(n, 6) if cov is not None else None
+            d_sh = new(*sh.shape) if (sh is not None and sink is None) else None
+            d_col = new(n, 3) if (col is not None or sink is not None) else None
+            d_rest = new(*sh_rest.shape) if (sh_rest is not None and d_sh is not None) else None
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             splats = _splats_struct(n, means3D, opac, sc, rot, cov, sh, col, ctx.raw_params, sh_rest)
             scratch = torch.empty(lib.sr_backward_scratch_bytes(ctx.capacity), dtype=torch.uint8, device=dev)
             p = lambda t: None if t is None else t.data_ptr()
             grads = _lib.SrGrads(p(d_means3D), p(d_means2D), p(d_opac), p(d_sc), p(d_rot), p(d_cov), p(d_sh), p(d_col), p(d_rest))
-            _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity, ctx.instances,
-                                       _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
-                                       _ptr(scratch), C.byref(grads), stream))
+            if hook is None:
+                _lib.check(lib.sr_backward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity, ctx.instances,
+                                           _ptr(image), _ptr(radii), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
+                                           _ptr(scratch), C.byref(grads), stream))
+            else:
+                _lib.check(lib.sr_backward_blend(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
+                                                 ctx.instances, _ptr(image), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha),
+                                                 _ptr(scratch), stream))
+                for j, (lo, hi) in enumerate(slice_ranges(n, hook.slices)):
+                    _lib.check(lib.sr_backward_splats(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
+                                                      _ptr(image), _ptr(radii), _ptr(scratch), C.byref(grads), lo, hi - lo, stream))
+                    hook.on_slice(j, lo, hi)
+        if hook is not None:
+            return (None, d_means2D) + (None,) * 11
         # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings
         if sink is not None:
             sink.append(d_col)  # clamp-masked dL/dcolour of this view; dL/dsh is rebuilt from all views by the caller
@@ -306,16 +330,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = [g_ if (g_ is None or dt is None or g_.dtype == dt) else g_.to(dt) for g_, dt in zip(grads, ctx.in_dtypes)]
         if d_rest is not None and ctx.rest_dtype is not None and d_rest.dtype != ctx.rest_dtype:
             d_rest = d_rest.to(ctx.rest_dtype)
-        return (*grads, None, None, None, d_rest)
+        return (*grads, None, None, None, d_rest, None)
+
+
+def slice_ranges(n: int, slices: int) -> list:
+    """[lo, hi) ranges of the sliced backward: `slices` pieces of equal size rounded up to a multiple of 256 splats (the
+    granule of the per-splat kernels); fewer pieces when the cloud is small."""
+    per = -(-n // max(int(slices), 1))          # ceil(n / slices)
+    per = max(256, -(-per // 256) * 256)        # ... rounded up to the granule
+    return [(lo, min(lo + per, n)) for lo in range(0, n, per)]
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, color_grad_sink=None, raw_params: int = 0, sh_rest=None):
+                        raster_settings, color_grad_sink=None, raw_params: int = 0, sh_rest=None, slice_hook=None):
     """Returns (color, radii, depth, alpha).  ``alpha`` (= 1 - final transmittance) is the fused equivalent of
     the reference's second rasterization with white colours on a black background
     (gaussian_renderer/__init__.py:104-115)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params, sh_rest)
+                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params, sh_rest, slice_hook)
 
 
 class GaussianRasterizer(nn.Module):
@@ -346,19 +378,24 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
     def forward_ex(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                   cov3D_precomp=None, color_grad_sink=None, shs_rest=None):
+                   cov3D_precomp=None, color_grad_sink=None, shs_rest=None, slice_hook=None):
         """Same as ``forward`` plus the fused alpha image: (color, radii, depth, alpha).
 
         ``color_grad_sink`` (a list, SH path only): the backward appends the clamp-masked dL/dcolour [N,3] of this view to
         it and returns no gradient for ``shs`` -- used by the view-parallel step, which exchanges colour gradients and
         rebuilds the SH gradient of all views locally (splatfields_amd/view_parallel.py).
 
+        ``slice_hook`` (view-parallel step only): an object with ``slices`` (int), ``buffers(n) -> dict`` of caller-owned gradient
+        tensors (``means3D, scales, rotations, opacities, colors``) and ``on_slice(j, lo, hi)``: the backward writes the
+        per-splat gradients of rows [lo, hi) into those buffers slice by slice and calls the hook behind every slice's launch,
+        so that the exchange of finished slices overlaps the rest of the backward; autograd receives only ``means2D``'s gradient.
+
         ``shs_rest``: pass the reference's two SH parameters as they are stored, ``shs=_features_dc`` [N,1,3] and
         ``shs_rest=_features_rest`` [N,15,3] (scene/gaussian_model.py:40-41), instead of ``get_features`` -- the per-iteration
         ``torch.cat`` (:79-82, 192 B/splat copied forward and split again in backward) disappears; each gets its gradient."""
         self._check(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, color_grad_sink, 0, shs_rest)
+                                   self.raster_settings, color_grad_sink, 0, shs_rest, slice_hook)
 
     def forward_raw(self, means3D, means2D, opacity_logits, shs=None, colors_precomp=None, log_scales=None, quaternions=None,
                     color_grad_sink=None, shs_rest=None):

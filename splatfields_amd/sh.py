@@ -71,9 +71,10 @@ def mask_clamped(dcolors: torch.Tensor, clamped: torch.Tensor) -> torch.Tensor:
 
 
 def sh_backward(means3D, shs, campos_views, dcolors_views, sh_degree: int, *, scale: float = 1.0, want_shs=True,
-                means_grad: torch.Tensor = None, accumulate_means: bool = True):
+                means_grad: torch.Tensor = None, accumulate_means: bool = True, out: torch.Tensor = None):
     """campos_views [V,3]; dcolors_views [V,N,3] (already masked).  Returns dL/dshs [N,K,3] (or None); adds the gradient
-    through the view directions into ``means_grad`` when given."""
+    through the view directions into ``means_grad`` when given.  ``out``: write dL/dshs into this contiguous float32 [N,K,3]
+    tensor (e.g. a row range of a larger gradient) instead of allocating it."""
     lib = _lib.load()
     dev = means3D.device
     m = means3D.detach().to(torch.float32).contiguous()
@@ -81,7 +82,9 @@ def sh_backward(means3D, shs, campos_views, dcolors_views, sh_degree: int, *, sc
     cp = campos_views.detach().to(device=dev, dtype=torch.float32).contiguous().reshape(-1, 3)
     dc = dcolors_views.detach().to(torch.float32).contiguous().reshape(cp.shape[0], m.shape[0], 3)
     n, k, v = m.shape[0], s.shape[1], cp.shape[0]
-    d_shs = torch.empty_like(s) if want_shs else None
+    d_shs = (out if out is not None else torch.empty_like(s)) if want_shs else None
+    if out is not None and not (out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == tuple(s.shape)):
+        raise RuntimeError("out must be a contiguous float32 tensor of the shape of shs")
     if means_grad is not None and not (means_grad.is_contiguous() and means_grad.dtype == torch.float32):
         raise RuntimeError("means_grad must be a contiguous float32 tensor")
     with torch.cuda.device(dev):

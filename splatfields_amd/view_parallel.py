@@ -107,6 +107,70 @@ def _nbytes(t: torch.Tensor) -> float:
     return float(t.numel() * t.element_size())
 
 
+# xGMI on an 8 x MI355X node: every GPU has 7 point-to-point links of ~153 GB/s (both directions together; ~76.8 GB/s each
+# way), one to each peer (/opt/skills/guides/MI355X_MICROARCH.md; the task statement's figure).  A collective that spreads
+# its traffic over all peers (RCCL's direct / multi-ring algorithms on a fully connected node) can therefore move at most
+# 7 x 153 = 1071 GB/s per GPU counting sent + received bytes, 537 GB/s counting the bytes a GPU SENDS (the ring model's
+# `wire_bytes_per_gpu`).  Measured RCCL bus bandwidths on this class of node are lower (~300 GB/s for 10-100 MB messages).
+XGMI_LINKS, XGMI_LINK_GBPS = 7, 153.0
+RCCL_TYPICAL_BUS_GBPS = 300.0
+
+
+def wire_bytes_per_gpu(mode: str, n_splats: int, world: int, sh_coeffs: int = 16, views_per_rank: int = 1) -> float:
+    """Bytes every GPU sends per step under the ring model ExchangeStats uses (all-reduce of S bytes: 2 (G-1)/G S; all-gather /
+    all-to-all of S bytes in total: (G-1)/G S), for the three exchange schemes of a step with `views_per_rank` views per rank."""
+    f = (world - 1) / world if world > 0 else 0.0
+    geo = 44.0 * n_splats                                    # means3D 12 + scales 12 + rotations 16 + opacity 4
+    if mode == "allreduce":
+        return 2.0 * f * (geo + 12.0 * sh_coeffs * n_splats)
+    if mode == "gather":
+        return f * (12.0 * n_splats * world * views_per_rank) + 2.0 * f * geo
+    if mode == "shard":
+        shard = -(-n_splats // world)
+        return 2.0 * f * (12.0 * shard * world * views_per_rank) + 2.0 * f * geo
+    raise ValueError(mode)
+
+
+def predict_scaling(mode: str, n_splats: int, world: int, compute_ms: float, *, tail_ms: float = 0.0, slices: int = 1,
+                    rebuild_ms: float = 0.0, sh_coeffs: int = 16) -> dict:
+    """What the first run on a multi-GPU node should show (bench.py's `predicted` block): the exchange time of one step from the
+    wire bytes and the link arithmetic above, how much of it the step hides, and the weak-scaling speed-up that follows (one view
+    per GPU) -- at the link peak (the yardstick: wire bytes / (7 links x 153 GB/s)), at the one-way peak, and at a bus bandwidth
+    RCCL typically reaches on such a node.
+
+    `compute_ms`: the single-GPU step.  `tail_ms`: the last part of it after which the data of the exchange is complete -- the
+    per-splat backward, which the gather scheme runs in `slices` ranges, starting every range's collectives behind it.
+    `rebuild_ms`: compute the scheme adds (the local SH-gradient rebuild; a range's rebuild needs its all-gather).
+    Timeline of the sliced gather step, with the wire kept busy from the first finished range on:
+        end = compute + max(rebuild, exchange - tail (1 - 1/slices) + rebuild / slices)
+    plain all-reduce (nothing to overlap with): end = compute + exchange;  sharded: end = compute + exchange + rebuild."""
+    wire = wire_bytes_per_gpu(mode, n_splats, world, sh_coeffs)
+    k = max(int(slices), 1)
+    out = {"dp_mode": mode, "world": world, "wire_bytes_per_gpu": wire, "wire_bytes_per_splat_per_gpu": wire / max(n_splats, 1),
+           "links": XGMI_LINKS, "link_GBps": XGMI_LINK_GBPS, "compute_ms": compute_ms, "tail_ms": tail_ms, "slices": k,
+           "rebuild_ms": rebuild_ms,
+           "model": "exchange_ms = wire bytes / bandwidth; gather: exposed = max(rebuild, exchange - tail (1 - 1/slices) + rebuild / slices); "
+                    "allreduce: exposed = exchange; shard: exposed = exchange + rebuild; step = compute + exposed; "
+                    "speed-up = world x compute / step (weak scaling, one view per GPU)"}
+    for name, gbps in (("link_peak", XGMI_LINKS * XGMI_LINK_GBPS), ("one_way_peak", 0.5 * XGMI_LINKS * XGMI_LINK_GBPS),
+                       ("rccl_typical", RCCL_TYPICAL_BUS_GBPS)):
+        ex = wire / (gbps * 1e9) * 1e3 if world > 1 else 0.0
+        if world <= 1:
+            exposed = 0.0
+        elif mode == "gather":
+            exposed = max(rebuild_ms, ex - tail_ms * (1.0 - 1.0 / k) + rebuild_ms / k)
+        elif mode == "shard":
+            exposed = ex + rebuild_ms
+        else:
+            exposed = ex
+        step = compute_ms + exposed
+        out[name] = {"bandwidth_GBps": gbps, "exchange_ms": ex, "exposed_exchange_ms": exposed, "step_ms": step,
+                     "speedup": world * compute_ms / step if step > 0 else None}
+    out["expected_exposed_exchange_ms"] = out["link_peak"]["exposed_exchange_ms"]
+    out["expected_speedup"] = out["link_peak"]["speedup"]
+    return out
+
+
 def pack_gradients(grads: Sequence[torch.Tensor]):
     """One flat buffer holding ``grads`` back to back (one `cat` kernel) and, per tensor, a view of its segment."""
     flat = torch.cat([g.reshape(-1) for g in grads])
@@ -196,8 +260,70 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, group=None, 
                 p.grad = None   # no rank had a gradient for it: as in the single-process loop, the optimizer skips it
 
 
+def _all_reduce_many(tensors: Sequence[torch.Tensor], group=None):
+    """SUM all-reduce of several contiguous tensors in place, asynchronously, as ONE launch where the backend can group them
+    (RCCL: ncclGroupStart / End through torch's coalescing manager -- the tensors stay where they are, no packing copy);
+    returns an object with .wait()."""
+    tensors = [t for t in tensors if t.numel() > 0]
+
+    class _Works:
+        def __init__(self, ws):
+            self.ws = ws
+
+        def wait(self):
+            for w in self.ws:
+                w.wait()
+
+    if dist.get_backend(group) == "nccl" and hasattr(dist, "_coalescing_manager") and tensors:
+        try:
+            with dist._coalescing_manager(group=group, device=tensors[0].device, async_ops=True) as cm:
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return _Works([cm])
+        except Exception:  # noqa: BLE001 -- an older torch without async coalescing: one collective per tensor below
+            pass
+    return _Works([dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in tensors])
+
+
+class _SlicedGatherHook:
+    """`slice_hook` of the rasterizer's backward for `sh_gather_step` (one view per rank): owns the gradient buffers, and behind
+    every slice of the per-splat backward starts that slice's two collectives -- the all-gather of its colour gradients and ONE
+    grouped sum all-reduce of its rows of the four geometric gradients, in place.  They run on RCCL's stream while the compute
+    stream goes on with the next slice (0.09 ms of per-splat backward at 1 M splats) and, afterwards, with the SH-gradient
+    rebuild of the slices whose colour gradients have arrived."""
+
+    def __init__(self, slices: int, world: int, group, dev):
+        self.slices, self.world, self.group, self.dev = int(slices), world, group, dev
+        self.buf = None
+        self.pending = []     # (lo, hi, gathered [world, hi - lo, 3], gather work, reduce works)
+        self.window = None    # ExchangeStats: opens when the first collective is issued (inside the backward)
+
+    def buffers(self, n: int) -> dict:
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.dev)
+        self.buf = {"means3D": new(n, 3), "scales": new(n, 3), "rotations": new(n, 4), "opacities": new(n, 1), "colors": new(n, 3)}
+        return self.buf
+
+    def on_slice(self, j: int, lo: int, hi: int) -> None:
+        b = self.buf
+        if self.window is None:
+            self.window = _Window(self.dev)
+            self.window.__enter__()
+        gathered = torch.empty(self.world, hi - lo, 3, dtype=torch.float32, device=self.dev)
+        gw = dist.all_gather_into_tensor(gathered.view(-1), b["colors"][lo:hi].reshape(-1), group=self.group, async_op=True)
+        ExchangeStats.note("all_gather", _nbytes(gathered), self.world)
+        geo = [b[k][lo:hi] for k in ("means3D", "scales", "rotations", "opacities")]
+        rw = _all_reduce_many(geo, self.group)
+        ExchangeStats.note("all_reduce", sum(_nbytes(t) for t in geo), self.world)
+        self.pending.append((lo, hi, gathered, gw, rw))
+
+
+# slices of the per-splat backward whose exchange is started while the rest is still being computed (sh_gather_step, one
+# view per rank); 1 = the unsliced exchange behind the whole backward
+GATHER_SLICES = 4
+
+
 def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn: Callable, *, scaling_modifier: float = 1.0,
-                   rank: int = None, world: int = None, group=None) -> None:
+                   rank: int = None, world: int = None, group=None, slices: int = None) -> None:
     """View-parallel step for the SH colour path with the low-rank gradient exchange.
 
     ``params``: dict of leaf tensors ``means3D, scales, rotations, opacities, shs`` (replicated on every rank).
@@ -208,7 +334,13 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     Afterwards every rank holds in ``p.grad`` the gradient of the mean loss over all V views -- the same result as
     all-reducing all five gradient tensors, but the 192 B/splat SH gradient never crosses xGMI: for one view it is
     basis(view direction) (x) dL/dcolour, so ranks all-gather the 12 B/splat colour gradients of all views and rebuild
-    the sum locally (sr_sh_backward).  Wire traffic per rank drops from ~413 to ~161 bytes per splat."""
+    the sum locally (sr_sh_backward).  Wire traffic per rank drops from ~413 to ~161 bytes per splat.
+
+    ``slices`` (default `GATHER_SLICES`; used when every rank renders exactly one view): the per-splat part of the rasterizer's
+    backward runs in that many splat ranges, and the exchange of a finished range -- all-gather of its colour gradients, one
+    grouped in-place all-reduce of its geometric gradients (no packing copy) -- is issued right behind it, so it overlaps the
+    remaining ranges and the SH-gradient rebuild of earlier ones.  Results are identical to the unsliced step (same kernels
+    per splat, same collectives per row)."""
     import math
     from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from . import sh as shmod
@@ -226,6 +358,9 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     dev = means3D.device
     n = means3D.shape[0]
     mine = list(range(rank, V, world))
+    slices = GATHER_SLICES if slices is None else int(slices)
+    if _exchange(world) and len(mine) == 1 and slices > 1 and n >= 512:
+        return _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_modifier, rank, world, group, slices, mine[0])
     dcol_views = []
     for slot, vi in enumerate(mine):
         cam = cams[vi]
@@ -268,6 +403,49 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
             params[k].grad = v
     else:
         params["shs"].grad = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
+
+
+def _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_modifier, rank, world, group, slices, vi) -> None:
+    """`sh_gather_step` with one view per rank and the exchange started slice by slice from inside the backward."""
+    import math
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from . import sh as shmod
+    names = ["means3D", "scales", "rotations", "opacities"]
+    means3D, shs = params["means3D"], params["shs"]
+    dev = means3D.device
+    V = len(cams)
+    cam = cams[vi]
+    rs = GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+    hook = _SlicedGatherHook(slices, world, group, dev)
+    sink = []
+    color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+        means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
+        shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink, slice_hook=hook)
+    campos_all = _campos_of(cams, dev)          # gathered[r] is view r (one view per rank: V == world)
+    d_shs = torch.empty_like(shs, dtype=torch.float32)
+    backward_fn(vi, color, depth, alpha)    # blend, then per slice: per-splat backward + hook.on_slice (collectives issued)
+    if hook.buf is None:                    # nothing reached the rasterizer's backward (zero upstream gradients)
+        hook.buffers(means3D.shape[0])
+        for t in hook.buf.values():
+            t.zero_()
+        from .rasterizer import slice_ranges
+        for j, (lo, hi) in enumerate(slice_ranges(means3D.shape[0], slices)):
+            hook.on_slice(j, lo, hi)
+    m_det, s_det = means3D.detach(), shs.detach()
+    for lo, hi, gathered, gw, rw in hook.pending:
+        gw.wait()
+        with _Window(dev, inner=True):
+            shmod.sh_backward(m_det[lo:hi], s_det[lo:hi], campos_all, gathered, sh_degree, want_shs=True, out=d_shs[lo:hi])
+    for _, _, _, _, rw in hook.pending:
+        rw.wait()
+    if hook.window is not None:
+        hook.window.__exit__(None, None, None)
+    for k in names:
+        params[k].grad = hook.buf[k].view(params[k].shape)
+    params["shs"].grad = d_shs
 
 
 _CAMPOS_CACHE: dict = {}

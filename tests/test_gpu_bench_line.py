@@ -66,8 +66,17 @@ def test_two_rank_line_carries_the_exchange_diagnostics(hip_device, mode):
               "wire_bytes_per_splat_per_gpu"):
         assert k in ex, k
     assert ex["dp_mode"] == mode and ex["rccl_ranks"] == 2
+    # the link-arithmetic prediction for an 8-GPU node rides in the same block (view_parallel.predict_scaling)
+    pr = ex["predicted"]
+    for k in ("wire_bytes_per_gpu", "links", "link_GBps", "compute_ms", "expected_exposed_exchange_ms", "expected_speedup", "link_peak",
+              "one_way_peak", "rccl_typical", "model"):
+        assert k in pr, k
+    assert pr["world"] == 8 and pr["links"] == 7 and pr["dp_mode"] == mode
+    assert abs(pr["link_peak"]["exchange_ms"] - pr["wire_bytes_per_gpu"] / (7 * 153e9) * 1e3) < 1e-9
+    assert 1.0 < pr["rccl_typical"]["speedup"] <= pr["one_way_peak"]["speedup"] <= pr["link_peak"]["speedup"] <= 8.0
+    assert "2" in ex["predicted_by_world"]
     assert ex["exchange_ms"] > 0.0 and 0.0 <= ex["overlap_ms"] <= ex["exchange_ms"]
-    assert abs(ex["compute_ms"] - (d["ms_per_step"] - ex["exchange_ms"] + ex["overlap_ms"])) < 1e-9
+    assert abs(ex["compute_ms"] - (d["ms_per_step_median"] - ex["exchange_ms"] + ex["overlap_ms"])) < 1e-9
     # ring model at 2 ranks: all-reduce of S moves S per GPU, all-gather / all-to-all of S in total S / 2
     n, geo = 20000, 44.0   # means3D 12 + scales 12 + rotations 16 + opacity 4 bytes per splat
     # gather: all-gather of 2 x 12 B/splat -> 12; shard: two all-to-alls of 12 B/splat -> 6 + 6; plain: 236 B/splat in one buffer

@@ -68,6 +68,17 @@ def test_every_exchange_scheme_runs_on_rccl(hip_device, rccl_group):
     for k in NAMES:
         close(p[k].grad, ref[k], ("gather", k))
 
+    # 1b. one view per rank: the SLICED exchange -- per range an all-gather and ONE grouped (ncclGroupStart / End) in-place
+    #     all-reduce of the four geometric gradients, issued from inside the backward
+    ref1 = _reference(sp, cams[:1], gi, gd, ga, dev)
+    for slices in (1, 4):
+        p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+        vp.sh_gather_step(p, cams[:1], bg, DEG, lambda vi, c, d, a: torch.autograd.backward((c, d, a), (gi, gd, ga)), rank=0, world=1,
+                          slices=slices)
+        torch.cuda.synchronize()
+        for k in NAMES:
+            close(p[k].grad, ref1[k], ("gather sliced", slices, k))
+
     # 2. SH sharded by splat range: two device all-to-all + packed all-reduce
     p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
     lo, hi, d_shs = vp.sh_sharded_step(p, cams, bg, DEG, bwd, rank=0, world=1)

@@ -70,7 +70,7 @@ def test_shs_path_equals_precomputed_colours_of_sh_stage(hip_device):
         assert torch.allclose(res[0][1][k], res[1][1][k], atol=2e-5 * scale), k
 
 
-def _reference_grads(dev, n=N):
+def _reference_grads(dev, n=N, V=V):
     """plain path: every view through the SH rasterizer, mean of the views, one backward (reference train.py:169-252)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     sp = make_splats(n, seed=7, device=dev)
@@ -85,7 +85,7 @@ def _reference_grads(dev, n=N):
     return {k: v.grad.detach().cpu() for k, v in p.items()}
 
 
-def _gather_grads(dev, rank, world):
+def _gather_grads(dev, rank, world, V=V, slices=None):
     from splatfields_amd.view_parallel import sh_gather_step
     sp = make_splats(N, seed=7, device=dev)
     p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
@@ -95,7 +95,7 @@ def _gather_grads(dev, rank, world):
     def bwd(vi, c, d, a):
         torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
 
-    sh_gather_step(p, cams, torch.ones(3, device=dev), DEG, bwd, rank=rank, world=world)
+    sh_gather_step(p, cams, torch.ones(3, device=dev), DEG, bwd, rank=rank, world=world, slices=slices)
     torch.cuda.synchronize()
     return {k: v.grad.detach().cpu() for k, v in p.items()}
 
@@ -110,12 +110,12 @@ def test_gather_step_single_rank_equals_plain_multiview(hip_device):
     _close(_gather_grads(hip_device, 0, 1), _reference_grads(hip_device))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, views=V, slices=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")  # both ranks share the single GPU of the test box; gloo moves the tensors
     torch.cuda.set_device(dev)
-    g = _gather_grads(dev, rank, world)
+    g = _gather_grads(dev, rank, world, views, slices)
     q.put((rank, {k: v.numpy().copy() for k, v in g.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -135,6 +135,74 @@ def test_gather_step_two_ranks_equals_plain_multiview(hip_device):
         assert p.exitcode == 0
     for rank, g in outs:
         _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
+
+
+@pytest.mark.parametrize("slices", [1, 3, 4])
+def test_sliced_gather_step_two_ranks_one_view_each(hip_device, slices):
+    """One view per rank (the 8-GPU bench's shape): the per-splat backward runs in `slices` ranges and every range's all-gather /
+    grouped all-reduce is issued behind it from inside the backward (view_parallel._SlicedGatherHook).  Same gradients as the
+    single-process two-view step, on both ranks, for the unsliced exchange (1) and for ranges that do (4: 1536 rows) and do
+    not (3: 2048 rows) divide the cloud evenly."""
+    ref = _reference_grads(hip_device, V=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 2, slices)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, g in outs:
+        _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
+    # both ranks hold bit-identical gradients (what replicated Adam needs)
+    for k in NAMES:
+        assert (outs[0][1][k] == outs[1][1][k]).all(), k
+
+
+def test_sliced_backward_equals_the_unsliced_one_bit_for_bit(hip_device):
+    """sr_backward_blend + sr_backward_splats over any partition == sr_backward (same kernels, same arithmetic per splat)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = hip_device
+    sp = make_splats(N, seed=9, device=dev)
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    cam = make_camera(3, W, H, device=dev)
+
+    class Hook:
+        def __init__(self, slices):
+            self.slices, self.buf, self.seen = slices, None, []
+
+        def buffers(self, n):
+            self.buf = {k: torch.full((n, c), float("nan"), device=dev) for k, c in
+                        (("means3D", 3), ("scales", 3), ("rotations", 4), ("opacities", 1), ("colors", 3))}
+            return self.buf
+
+        def on_slice(self, j, lo, hi):
+            self.seen.append((j, lo, hi))
+
+    def run(hook):
+        p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+        sink = []
+        c, r, d, a = GaussianRasterizer(_rs(cam, dev)).forward_ex(means3D=p["means3D"], means2D=m2, opacities=p["opacities"], shs=p["shs"],
+                                                                  scales=p["scales"], rotations=p["rotations"], color_grad_sink=sink,
+                                                                  slice_hook=hook)
+        torch.autograd.backward((c, d, a), (gi, gd, ga))
+        if hook is None:
+            return {"means3D": p["means3D"].grad, "scales": p["scales"].grad, "rotations": p["rotations"].grad,
+                    "opacities": p["opacities"].grad, "colors": sink[0], "means2D": m2.grad}
+        assert all(p[k].grad is None for k in NAMES)          # the hook's owner sets .grad
+        return dict(hook.buf, means2D=m2.grad)
+
+    whole = run(None)
+    for k in (1, 2, 5):
+        h = Hook(k)
+        part = run(h)
+        assert [x[0] for x in h.seen] == list(range(len(h.seen))) and h.seen[0][1] == 0 and h.seen[-1][2] == N
+        assert all(lo % 256 == 0 for _, lo, _ in h.seen) and all(a[2] == b[1] for a, b in zip(h.seen, h.seen[1:]))
+        for name in whole:
+            assert torch.equal(part[name], whole[name]), (k, name)
 
 
 # ---- SH-sharded step: colours / colour gradients travel by all-to-all, each rank owns a slice of the SH tensor ----
