@@ -15,6 +15,15 @@ import torch
 
 from test_general_mlp import GOLDEN, formula
 
+
+def formula_points(xyz, feat, multires, weights, biases, skips=(), negative_slope=0.01, _shape=None, time=None, time_multires=0):
+    """what fused_general_mlp_points computes, in plain PyTorch: the reference's input assembly (utils/time_utils.py:9-57,
+    178-181: positional encoding of the positions, features behind it, the time embedding last) + the layer formula"""
+    from splatfields_amd.general_mlp import positional_encoding
+    parts = [positional_encoding(xyz, multires)] + ([feat] if feat is not None else []) + \
+        ([positional_encoding(time.reshape(-1, 1), time_multires)] if time is not None else [])
+    return formula(torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0], weights, biases, skips, negative_slope)
+
 CASES = sorted(os.path.basename(p)[len("splatfields_"):-len(".npz")] for p in glob.glob(os.path.join(GOLDEN, "splatfields_*.npz")))
 
 
@@ -160,6 +169,7 @@ def test_network_into_rasterizer_one_backward(hip_device, monkeypatch):
 
     img_a, vis_a, ga_ = step()
     monkeypatch.setattr(general_mlp, "fused_general_mlp", formula)
+    monkeypatch.setattr(general_mlp, "fused_general_mlp_points", formula_points)   # the path device tensors take
     img_b, vis_b, gb_ = step()
     assert vis_a > n // 4 and abs(vis_a - vis_b) <= 2
     assert (img_a - img_b).abs().max().item() <= 1e-3
@@ -167,6 +177,72 @@ def test_network_into_rasterizer_one_backward(hip_device, monkeypatch):
     for k in ga_:
         num, den = (ga_[k] - gb_[k]).norm().item(), gb_[k].norm().item()
         assert num <= 1e-2 * den + 1e-12, (k, num, den)      # wiring test; precision is pinned by the fixture tests above
+
+
+@pytest.mark.gpu
+def test_config5_full_size_step_is_deterministic_and_matches_the_formula_path(hip_device, monkeypatch):
+    """BASELINE.json configs[4] at FULL size on one GPU (reference train.py:62-101, utils/time_utils.py:467-508, run_owlii.sh:7):
+    100 k points at one of 50 frames -> the product `SplatFields` (tri-plane sampler + refine MLP, six ResField MLPs with
+    composition rank > 0, flow head) -> the rasterizer at 800x800 on precomputed colours (train.py:80-81, scales as a residual,
+    :74) -> one backward through both.
+      * deterministic: the step run twice gives bit-identical images, position gradients and parameter gradients (no
+        floating-point atomic anywhere: slot reduction, tri-plane scatter in 64-bit fixed point, slab sums in fixed order);
+      * the fused MLP kernels agree with their PyTorch formula inside the same step: images, and the gradient of every one of
+        the network's parameter tensors."""
+    import math
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd import general_mlp
+    from splatfields_amd.deform_field import SplatFields
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    dev = hip_device
+    n, W, H = 100_000, 800, 800
+    torch.manual_seed(5)
+    net = SplatFields(radius=None, n_frames=50, composition_rank=10, flow_model="offset", encoder_args={"noise_res": 20}).to(dev)
+    assert net.feat_dim == 48 and tuple(net.encoder.planes.shape) == (3, 16, 320, 320)
+    with torch.no_grad():
+        net.encoder.planes.normal_(0.0, 0.3)                 # a free-plane sampler starts at zero features: give the lookup something to do
+    sp = make_splats(n, seed=23, device=dev)
+    xyz = sp["means3D"].clone().requires_grad_(True)
+    t = torch.full((n, 1), 17.0 / 49.0, device=dev)          # frame 17 of 50
+    cam = make_camera(3, W, H, device=dev)
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), torch.ones(3, device=dev), 1.0,
+                                       cam.world_view_transform, cam.full_proj_transform, 0, cam.camera_center, False, False)
+    params = dict(net.named_parameters())
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        xyz.grad = None
+        out = net(xyz, t)
+        scales = sp["scales"] + 0.01 * out["scales"]
+        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+            means3D=out["means3D"], means2D=torch.zeros_like(xyz, requires_grad=True), opacities=out["opacity"], colors_precomp=out["rgb"],
+            scales=scales, rotations=out["rotations"])
+        torch.autograd.backward((color, depth, alpha), (gi, gd, ga))
+        grads = {k: p.grad.clone() for k, p in params.items() if p.grad is not None}
+        grads["xyz"] = xyz.grad.clone()
+        return color.detach().clone(), depth.detach().clone(), int((radii > 0).sum()), grads
+
+    img_a, dep_a, vis_a, g_a = step()
+    img_b, dep_b, vis_b, g_b = step()
+    assert vis_a > n // 2 and vis_a == vis_b
+    assert torch.equal(img_a, img_b) and torch.equal(dep_a, dep_b)
+    assert set(g_a) == set(g_b) and len(g_a) > 60
+    for k in g_a:
+        assert torch.equal(g_a[k], g_b[k]), k
+    for must in ("encoder.planes", "mlp_refine_feat.0.weight", "mlp_deform.net.3.matrix_t", "mlp_deform.net.3.weights_t", "mlp_rgb.net.0.weight",
+                 "mlp_flow_head.gaussian_warp.weight", "mlp_scale.net.2.matrix_t", "mlp_opacity.net.5.bias", "mlp_rotation.net.4.weight"):
+        assert must in g_a and torch.isfinite(g_a[must]).all() and g_a[must].abs().max() > 0, must
+    monkeypatch.setattr(general_mlp, "fused_general_mlp", formula)
+    monkeypatch.setattr(general_mlp, "fused_general_mlp_points", formula_points)
+    img_f, dep_f, vis_f, g_f = step()
+    assert abs(vis_f - vis_a) <= 20
+    assert (img_f - img_a).abs().max().item() <= 2e-3 and (img_f - img_a).abs().mean().item() <= 2e-5
+    assert set(g_f) == set(g_a)
+    for k in g_a:
+        num, den = (g_a[k] - g_f[k]).norm().item(), g_f[k].norm().item()
+        assert num <= 1e-2 * den + 1e-12, (k, num, den)   # leaky-ReLU units within rounding of 0 take the other branch (DESIGN.md section 8)
 
 
 def test_learning_rate_schedule_known_values():
