@@ -139,6 +139,20 @@ template <bool UP> __device__ __forceinline__ float shift_in_carry(float carry, 
 }
 #endif
 
+// x, y hold two different quantities per lane.  swap32: r[l] = x[l] + x[l + 32] for l < 32, y[l - 32] + y[l] above (one
+// v_permlane32_swap + one add: each half-wave now owns one quantity); swap16 the same one level down (rows 0, 2 own x, rows
+// 1, 3 own y).  Two levels sum FOUR per-lane quantities over the four rows of a wavefront with three swap-adds:
+//   w = swap16(swap32(a, b), swap32(c, d)):   row 0: sum a,  row 1: sum c,  row 2: sum b,  row 3: sum d     (per lane n = lane & 15)
+typedef unsigned int uint2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap32_sum(float x, float y) {
+    const uint2q r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap16_sum(float x, float y) {
+    const uint2q r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 __device__ __forceinline__ uint32_t row_allsum_u32(uint32_t v) {   // every lane of a row: the row's sum
     v += dpp_u<0xB1>(0u, v); v += dpp_u<0x4E>(0u, v); v += dpp_u<0x124>(0u, v); v += dpp_u<0x128>(0u, v);
     return v;
@@ -154,36 +168,43 @@ __device__ __forceinline__ uint32_t row_scan_add_u32(uint32_t x) {
 struct BwdEntry {
     int pos;            // list position (descending with the thread index), < 0: none
     float2 c;           // splat centre in pixels
-    float2 ef;          // (E0, F0): the per-(tile, entry) part of the exponent (common.h: exponent_terms)
-    float4 r1, r2;      // record quarters (p, p s [s in the record], q, -log2 o) (r, g, b, depth)
+    float2 ef;          // (E0, F0): the per-(tile, entry) part of the exponent (common.h: exponent_terms); set by finish_entry
+    float4 r1, r2;      // record quarters (p, s -> p s after finish_entry, q, -log2 o) (r, g, b, depth)
     uint32_t qm;        // quad-reach mask the forward computed for this (tile, entry)
-    uint32_t inst;      // instance index of the (splat, tile) pair: slot of the gradient scratch
+    uint32_t inst;      // instance index of the (splat, tile) pair: slot of the gradient scratch (after finish_entry)
+    uint32_t rect_xy, rect_w, first_rel;   // raw record quarter 3 until finish_entry
 };
 
 // Positions are clamped to 0 so that every load is unconditional (a thread without an entry loads entry 0 and drops it
 // through pos < 0): no branch, no merge with zeros behind the loads.
-__device__ __forceinline__ BwdEntry load_entry(const Geom& g, const uint32_t* ids, const uint32_t* qms, int pos, uint32_t tx, uint32_t ty) {
+// The gather is split in two so that nothing WAITS where it is issued: load_entry only requests -- the splat index `id` comes
+// from a load issued a whole chunk earlier (the record address depends on it: requested here, it was a full memory round trip
+// of ~1-2 us per chunk in which the wavefront did nothing) -- and finish_entry does the arithmetic on the loaded values where
+// they are first needed (the scatter, two phases later).
+__device__ __forceinline__ BwdEntry load_entry(const Geom& g, uint32_t id, const uint32_t* qms, int pos) {
     BwdEntry e;
     const int pc = pos > 0 ? pos : 0;
-    const uint32_t id = ids[pc];
     const float4* rec = g.rec + 4 * (size_t)id;
     e.pos = pos;
     e.c = *reinterpret_cast<const float2*>(rec);
     e.r1 = rec[1]; e.r2 = rec[2];
-    {   // what the forward's staging thread did with the same record (render.hip): same function, same inputs, same bits
-        float E0, F0, ps;
-        exponent_terms(e.c.x, e.c.y, e.r1, (float)(tx * kTile), (float)(ty * kTile), E0, F0, ps);
-        e.ef = make_float2(E0, F0);
-        e.r1.y = ps;
-    }
-    const float4 r3 = rec[3];   // (tile rect origin, rect width, first instance relative to the splat's 256-splat sub-batch): the
-                                // instance index = the splat's first instance + the tile's row-major position in its rect
-    const uint32_t rect_xy = __float_as_uint(r3.x), rect_w = __float_as_uint(r3.y);
+    const float4 r3 = rec[3];   // (tile rect origin, rect width, first instance relative to the splat's 256-splat sub-batch)
+    e.rect_xy = __float_as_uint(r3.x); e.rect_w = __float_as_uint(r3.y); e.first_rel = __float_as_uint(r3.z);
     // block_offsets is a 4 B x N / 256 table (16 KB at 1 M splats: cache resident); the per-splat `offsets` array would cost a
     // line of memory traffic per list entry for 4 useful bytes
-    e.inst = g.block_offsets[id >> 8] + __float_as_uint(r3.z) + (ty - (rect_xy >> 16)) * rect_w + (tx - (rect_xy & 0xffffu));
+    e.inst = g.block_offsets[id >> 8];
+    e.ef = make_float2(0.f, 0.f);
     e.qm = qms[pc];
     return e;
+}
+__device__ __forceinline__ void finish_entry(BwdEntry& e, uint32_t tx, uint32_t ty) {
+    // what the forward's staging thread did with the same record (render.hip): same function, same inputs, same bits
+    float E0, F0, ps;
+    exponent_terms(e.c.x, e.c.y, e.r1, (float)(tx * kTile), (float)(ty * kTile), E0, F0, ps);
+    e.ef = make_float2(E0, F0);
+    e.r1.y = ps;
+    // the instance index = the splat's first instance + the tile's row-major position in its rect
+    e.inst += e.first_rel + (ty - (e.rect_xy >> 16)) * e.rect_w + (tx - (e.rect_xy & 0xffffu));
 }
 
 // ---- the LDS slot of one (quad, entry) pair -------------------------------------------------------------------------
@@ -237,32 +258,33 @@ __device__ __forceinline__ void slot_mask_invalid(SlotIn& r, bool valid) {
     r.p = valid ? r.p : 0.f; r.ps = valid ? r.ps : 0.f; r.q = valid ? r.q : 0.f;
     r.r = valid ? r.r : 0.f; r.g = valid ? r.g : 0.f; r.b = valid ? r.b : 0.f; r.depth = valid ? r.depth : 0.f;
 }
-// rows 4 k .. 4 k + 3 of the 16 x 16 result (k = lane >> 4 < 3) -> floats [4 k, 4 k + 3] of the slot
-template <bool HAS_D>
-__device__ __forceinline__ void slot_put_sums(float* sl, int k, const f32x4 d) {
-    if constexpr (HAS_D) {
-        reinterpret_cast<float4*>(sl)[k] = make_float4(d[0], d[1], d[2], d[3]);
-    } else {
-        float2* o = reinterpret_cast<float2*>(sl) + 2 * k;
-        o[0] = make_float2(d[0], d[1]);
-        if (k < 2) o[1] = make_float2(d[2], d[3]);
-    }
+// The ten sums of a (quad, entry) pair leave the replay spread over the four rows of the wavefront (replay_bucket: three
+// registers per lane), and are stored where their row finds them with one 8-byte and at most one 4-byte store:
+//   floats  [0] M0  [1] MXY  [2] db  |  [3] MX  [4] MYY  [5] d(depth)  |  [6] MY  [7] dr  |  [8] MXX  [9] dg
+//            row 0 (w0, w1, w2)         row 2 (w0, w1, w2)                 row 1 (w0, w1)     row 3 (w0, w1)
+struct BucketSums { float w0, w1, w2; };
+__device__ __forceinline__ void slot_put_sums(float* sl, int row, const BucketSums d) {
+    const int o64 = row == 0 ? 0 : row == 1 ? 6 : row == 2 ? 4 : 8;
+    *reinterpret_cast<float2*>(sl + o64) = row == 2 ? make_float2(d.w1, d.w2) : make_float2(d.w0, d.w1);
+    if ((row & 1) == 0) sl[row == 0 ? 2 : 3] = row == 0 ? d.w2 : d.w0;
 }
+// -> a = (M0, MX, MY, MXX), b = (MXY, MYY, dr, dg), c = (db, d depth)
 template <bool HAS_D>
 __device__ __forceinline__ void slot_get_sums(const float* sl, float4& a, float4& b, float2& c) {
     if constexpr (HAS_D) {
         const float4* d = reinterpret_cast<const float4*>(sl);
-        a = d[0]; b = d[1]; const float4 t = d[2]; c = make_float2(t.x, t.y);
+        const float4 x = d[0], y = d[1], z = d[2];
+        a = make_float4(x.x, x.w, y.z, z.x); b = make_float4(x.y, y.x, y.w, z.y); c = make_float2(x.z, y.y);
     } else {
         const float2* d = reinterpret_cast<const float2*>(sl);
-        const float2 x0 = d[0], x1 = d[1], x2 = d[2], x3 = d[3];
-        a = make_float4(x0.x, x0.y, x1.x, x1.y); b = make_float4(x2.x, x2.y, x3.x, x3.y); c = d[4];
+        const float2 x0 = d[0], x1 = d[1], x2 = d[2], x3 = d[3], x4 = d[4];
+        a = make_float4(x0.x, x1.y, x3.x, x4.x); b = make_float4(x0.y, x2.x, x3.y, x4.y); c = make_float2(x1.x, x2.y);
     }
 }
 
 // Per-quad constants of the replay (pixel row k of the quad, pixel columns t = 0..3).
 struct QuadCtx {
-    float gR[4], gG[4], gB[4], gD[4], gA[4], A1[4], A2[4];
+    float gR[4], gG[4], gB[4], gD[4], gA[4];
     int last[4];
     float X0, Y;   // tile-relative pixel coordinates: column t of the quad is X0 + t, this lane's row is Y
 };
@@ -314,7 +336,7 @@ template <bool UP> __device__ __forceinline__ void row_scan_add4(float (&x)[4]) 
 }
 
 template <bool UP, bool HAS_D>
-__device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e, float ST[4], float SB[4], f32x4& D1, f32x4& D2, int lane) {
+__device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const SlotIn& e, float ST[4], float SB[4], int lane) {
     float oG[4], oGc[4], alpha[4], ginv[4], x[4], T[4], wgt[4], cgv[4], z[4], y[4];
     // opacity * G of the four pixels of this row: the forward's expression (common.h: pair_alpha_row / pair_alpha_px), so both
     // passes make the same alpha >= 1/255 decisions; the row part is shared by the four columns
@@ -366,6 +388,15 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e,
 #if !(SR_BWD_DIAG & 32)
     row_scan_add4<UP>(y);
 #endif
+    // The ten sums over the quad's pixels.  Per lane (one pixel row, four columns): moments of g1 in X about the tile centre
+    // and the colour / depth sums of the weights; the row's Y is a per-lane constant applied afterwards; then the four rows of
+    // the wavefront are added with eight swap-adds (swap32_sum / swap16_sum).
+    // (Rounds 2-3 did this with two v_mfma_f32_16x16x4_f32 per column -- "the reduction on the matrix cores".  Measured in
+    // round 4 (tools/mfma_valu_coissue.hip): on gfx950 the fp32 MFMA does NOT run beside the SIMD's VALU instructions, whichever
+    // wavefront issues them -- 16 v_fma + 2 MFMA per group take 445 cycles at four wavefronts per SIMD, 154 + 257 apart: it
+    // occupies the vector ALUs for its 32 cycles.  Eight of them per bucket were 256 of the bucket's ~880 cycles for 640 useful
+    // multiply-adds per lane-row; the same sums cost ~31 VALU instructions + 8 swap-adds, ~170 cycles.)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, br = 0.f, bg = 0.f, bb = 0.f, bd = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float behind = y[t];
@@ -373,18 +404,20 @@ __device__ __forceinline__ void replay_bucket(const QuadCtx& c, const SlotIn& e,
         // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
         const float dLa = T[t] * cgv[t] - ginv[t] * behind;
         const float g1 = oGc[t] * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
-#if SR_BWD_DIAG & 16
-        D1[t] += c.A1[t] * g1; D2[t] += c.A2[t] * wgt[t];   // timing experiment: no MFMA
-#else
-        // (Both contractions into ONE accumulator, the four that only need the weights issued right behind the product scan and
-        // the sums stored a bucket later -- so that no matrix instruction is waited for -- was measured in round 4: 0.2502 vs
-        // 0.2477 ms, not better: what the matrix instructions cost, 0.037 of 0.18 ms in a build without them, is the pipe time
-        // itself -- 8 x 32 cycles per bucket on the SIMD's one matrix pipe, shared by its three wavefronts.)
-        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A1[t], g1, D1, 0, 0, 0);
-        D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c.A2[t], wgt[t], D2, 0, 0, 0);
-#endif
+        const float X = c.X0 + ((float)t - 7.5f);   // wave-uniform
+        a0 += g1; a1 = fmaf(g1, X, a1); a2 = fmaf(g1, X * X, a2);
+        br = fmaf(wgt[t], c.gR[t], br); bg = fmaf(wgt[t], c.gG[t], bg); bb = fmaf(wgt[t], c.gB[t], bb);
+        if (HAS_D) bd = fmaf(wgt[t], c.gD[t], bd);
     }
+    const float Yc = c.Y - 7.5f;
+    const float mY = Yc * a0, mXY = Yc * a1, mYY = Yc * mY;
+    BucketSums r;
+    r.w0 = swap16_sum(swap32_sum(a0, a1), swap32_sum(mY, a2));     // rows 0..3: M0, MY, MX, MXX
+    r.w1 = swap16_sum(swap32_sum(mXY, mYY), swap32_sum(br, bg));   //            MXY, dr, MYY, dg
+    const float zz = swap32_sum(bb, bd);
+    r.w2 = swap16_sum(zz, zz);                                      //            db, -, d(depth), -
     (void)lane;
+    return r;
 }
 
 // HAS_D: the caller supplied dL/ddepth.  SplatFields' default losses leave the depth gradient empty (reference
@@ -443,7 +476,8 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
     if (bmax == 0) return;   // uniform: empty list, or no pixel of the tile blended anything
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
     const uint32_t* qms = b.qmask + start;
-    BwdEntry cur = load_entry(g, ids, qms, hi - 1 - tid, (uint32_t)tx, (uint32_t)ty);
+    BwdEntry cur = load_entry(g, ids[max(hi - 1 - tid, 0)], qms, hi - 1 - tid);
+    uint32_t id_next = ids[max(hi - kChunk - 1 - tid, 0)];   // its splat index: loaded another chunk earlier
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -544,11 +578,31 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
         float4 s0 = zero4, s1 = zero4;
         float2 s2 = make_float2(0.f, 0.f);
         pass_starts = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass_starts) | 0x10000u;   // sentinel: "pass" 17 starts at 16
+        uint32_t last_pmask = 0u;
+        auto combine = [&](uint32_t pmask) {
+            if (cur.pos >= 0) {
+                uint32_t m = qm & pmask;
+#if SR_BWD_DIAG & 2
+                m = 0u;   // timing experiment: no gather of the sums
+#endif
+                while (m) {
+                    const int q = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
+                    float4 a, cc; float2 d;
+                    slot_get_sums<HAS_D>(s_slot + kF * slot, a, cc, d);
+                    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                    s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
+                    s2.x += d.x; if (HAS_D) s2.y += d.y;
+                }
+            }
+        };
 #pragma unroll 1
         for (int q_lo = 0; q_lo < 16;) {
             const int q_hi = __builtin_ctz(pass_starts & ~((2u << q_lo) - 1u));   // next pass start behind q_lo
             const uint32_t pmask = ((1u << q_hi) - 1u) & ~((1u << q_lo) - 1u);
             // ---------------- (C) scatter the records into the quads' slot runs ----------------
+            if (q_lo == 0) finish_entry(cur, (uint32_t)tx, (uint32_t)ty);   // first use of the gathered record
             {
                 uint32_t m = qm & pmask;
 #if SR_BWD_DIAG & 2
@@ -588,21 +642,11 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 float ST[4], SB[4];
                 c.Y = (float)(4 * qy + k);
                 c.X0 = (float)(4 * qx);
-                const float Y = (float)(4 * qy + k) - 7.5f;
-                // MFMA A operands: this lane supplies row m = lane & 15 of the 16 x 4 operand for pixel row k.
-                // rows 0-5: pixel monomials 1, X, Y, X^2, XY, Y^2 = c0 + X (c1 + X c2); rows 6-9: dL/d(r, g, b, depth)
-                const float c0 = nl == 0 ? 1.0f : nl == 2 ? Y : nl == 5 ? Y * Y : 0.0f;
-                const float c1 = nl == 1 ? 1.0f : nl == 4 ? Y : 0.0f;
-                const float c2 = nl == 3 ? 1.0f : 0.0f;
-                const float w6 = nl == 6 ? 1.0f : 0.0f, w7 = nl == 7 ? 1.0f : 0.0f, w8 = nl == 8 ? 1.0f : 0.0f, w9 = nl == 9 ? 1.0f : 0.0f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
                     c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
                     c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
-                    const float X = (float)(4 * qx + t) - 7.5f;
-                    c.A1[t] = fmaf(X, fmaf(X, c2, c1), c0);
-                    c.A2[t] = fmaf(w9, a.w, fmaf(w8, a.z, fmaf(w7, a.y, w6 * a.x)));
                 }
                 // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
                 // interleave.  The slots of the next iteration are read while this one computes.
@@ -619,17 +663,13 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                     const SlotIn na = slot_get_record<HAS_D>(sa_n), nb = slot_get_record<HAS_D>(sb_n);
                     const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
                     slot_mask_invalid(eb, vb);
-                    f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a, D1b = D1a, D2b = D1a;
 #ifdef SR_BWD_STATS
                     if (lane == 0) { SR_STAT_ADD(2, 2); SR_STAT_ADD(3, 16 * (kBucket + min(kBucket, len - i0 - kBucket))); }
 #endif
-                    replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
-                    replay_bucket<false, HAS_D>(c, eb, ST, SB, D1b, D2b, lane);
-                    // D rows 4k..4k+3 of entry column n live in lane (k, n): rows 0-5 moments, 6-9 colour / depth sums
-                    if (k < 3) {
-                        slot_put_sums<HAS_D>(sa, k, D1a + D2a);
-                        if (vb) slot_put_sums<HAS_D>(sb, k, D1b + D2b);
-                    }
+                    const BucketSums Da = replay_bucket<true, HAS_D>(c, ea, ST, SB, lane);
+                    const BucketSums Db = replay_bucket<false, HAS_D>(c, eb, ST, SB, lane);
+                    slot_put_sums(sa, k, Da);
+                    if (vb) slot_put_sums(sb, k, Db);
                     sa = sa_n; sb = sb_n;
                     ea = na; eb = nb;
                 }
@@ -637,12 +677,11 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 if (tail) {
                     const bool va = i0 + nl < len;
                     slot_mask_invalid(ea, va);
-                    f32x4 D1a = {0.f, 0.f, 0.f, 0.f}, D2a = D1a;
 #ifdef SR_BWD_STATS
                     if (lane == 0) { SR_STAT_ADD(2, 1); SR_STAT_ADD(3, 16 * min(kBucket, len - i0)); }
 #endif
-                    replay_bucket<true, HAS_D>(c, ea, ST, SB, D1a, D2a, lane);
-                    if (k < 3 && va) slot_put_sums<HAS_D>(sa, k, D1a + D2a);
+                    const BucketSums Da = replay_bucket<true, HAS_D>(c, ea, ST, SB, lane);
+                    if (va) slot_put_sums(sa, k, Da);
                 }
                 if (nl == (tail ? 15 : 0)) {
 #pragma unroll
@@ -656,25 +695,12 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             lds_barrier();
             SR_PHASE(6);   // barrier after (D)
             // ---------------- (E) add up the quads' sums of every entry (ascending quad index: fixed summation order) ----------
-            if (cur.pos >= 0) {
-                uint32_t m = qm & pmask;
-#if SR_BWD_DIAG & 2
-                m = 0u;   // timing experiment: no gather of the sums
-#endif
-                while (m) {
-                    const int q = __builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t slot = (uint32_t)s_bb[par][q][myblk] + (uint32_t)__popc(s_mask[par][q][myblk] & lt_mask);
-                    float4 a, cc; float2 d;
-                    slot_get_sums<HAS_D>(s_slot + kF * slot, a, cc, d);
-                    s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-                    s1.x += cc.x; s1.y += cc.y; s1.z += cc.z; s1.w += cc.w;
-                    s2.x += d.x; if (HAS_D) s2.y += d.y;
-                }
-            }
-            if (q_hi < 16) lds_barrier();   // the next pass overwrites the slots
+            if (q_hi == 16) { last_pmask = pmask; break; }   // the last pass: combined below, behind the next chunk's requests
+            combine(pmask);
+            lds_barrier();   // the next pass overwrites the slots
             q_lo = q_hi;
         }
+        combine(last_pmask);
         // no barrier here: the next chunk's (A) touches only the other copy of the small tables, and its scatter (C) comes
         // after the barrier that follows (A)
         hi -= kChunk;
@@ -684,11 +710,6 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
         const float2 centre = cur.c;
         const size_t inst = cur.inst;
         const bool has_entry = cur.pos >= 0;
-#if SR_BWD_DIAG & 4
-        if (hi > 0) cur.pos = hi - 1 - tid;   // timing experiment: no gather for the following chunks
-#else
-        if (hi > 0) cur = load_entry(g, ids, qms, hi - 1 - tid, (uint32_t)tx, (uint32_t)ty);   // uniform condition
-#endif
         // shift the moments to the splat centre and store the instance's gradient slot
 #if SR_BWD_DIAG & 8
         if (has_entry && s0.x == 12345.678f) {   // timing experiment: (practically) no slot stores
@@ -707,6 +728,14 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
             slot4[inst * kSlotF4 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
             b.reached[inst] = 1;
         }
+#if SR_BWD_DIAG & 4
+        if (hi > 0) cur.pos = hi - 1 - tid;   // timing experiment: no gather for the following chunks
+#else
+        if (hi > 0) {   // uniform condition
+            cur = load_entry(g, id_next, qms, hi - 1 - tid);
+            id_next = ids[max(hi - kChunk - 1 - tid, 0)];
+        }
+#endif
         SR_PHASE(7);   // (E) combine
     }
 #ifdef SR_BWD_STATS
