@@ -250,12 +250,12 @@ __device__ __forceinline__ SlotIn slot_get_record(const float* sl) {
     }
     return r;
 }
-// a lane without an entry: alpha = 0 (only the exponent offset decides; the rest of the stale slot is kept finite)
+// A lane without an entry (it sees the next run's slot, or the slack behind the buffer): its exponent offset becomes +inf, so
+// opacity * G is 0 or NaN whatever the other exponent terms hold, the `hit` select turns either into alpha = G = 0, and the
+// lane is transparent to the scans; the colour (and depth) must be finite, because 0 * inf would poison the sum scan.
+// (Five selects per bucket instead of the eleven that cleaned every field: 27 of a bucket's ~750 VALU cycles.)
 __device__ __forceinline__ void slot_mask_invalid(SlotIn& r, bool valid) {
     r.nlo = valid ? r.nlo : __builtin_inff();
-    r.pos = valid ? r.pos : 0x7fffffff;
-    r.E0 = valid ? r.E0 : 0.f; r.F0 = valid ? r.F0 : 0.f;
-    r.p = valid ? r.p : 0.f; r.ps = valid ? r.ps : 0.f; r.q = valid ? r.q : 0.f;
     r.r = valid ? r.r : 0.f; r.g = valid ? r.g : 0.f; r.b = valid ? r.b : 0.f; r.depth = valid ? r.depth : 0.f;
 }
 // The ten sums of a (quad, entry) pair leave the replay spread over the four rows of the wavefront (replay_bucket: three
@@ -282,11 +282,18 @@ __device__ __forceinline__ void slot_get_sums(const float* sl, float4& a, float4
     }
 }
 
+// tile-relative column x = 0..15: (x, x - 7.5, (x - 7.5)^2) -- read with scalar loads by the (wave-uniform) quad column
+__constant__ float kColumn[3][16] = {
+    {0.f, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f, 9.f, 10.f, 11.f, 12.f, 13.f, 14.f, 15.f},
+    {-7.5f, -6.5f, -5.5f, -4.5f, -3.5f, -2.5f, -1.5f, -0.5f, 0.5f, 1.5f, 2.5f, 3.5f, 4.5f, 5.5f, 6.5f, 7.5f},
+    {56.25f, 42.25f, 30.25f, 20.25f, 12.25f, 6.25f, 2.25f, 0.25f, 0.25f, 2.25f, 6.25f, 12.25f, 20.25f, 30.25f, 42.25f, 56.25f}};
+
 // Per-quad constants of the replay (pixel row k of the quad, pixel columns t = 0..3).
 struct QuadCtx {
     float gR[4], gG[4], gB[4], gD[4], gA[4];
     int last[4];
-    float X0, Y;   // tile-relative pixel coordinates: column t of the quad is X0 + t, this lane's row is Y
+    float Y;                    // tile-relative row of this lane's pixels
+    float Xa[4], Xc[4], Xc2[4];   // per column, wave-uniform (scalar registers): tile-relative X, X about the tile centre, its square
 };
 
 // One bucket: 16 entries (lanes n) x 4 pixel rows (k) x 4 pixel columns (steps).  ST / SB carry the transmittance and
@@ -343,10 +350,10 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
     float G0, K;
     pair_alpha_row(c.Y, e.E0, e.F0, e.ps, e.q, e.nlo, G0, K);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_px(c.X0 + (float)t, e.p, G0, K);
+    for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_px(c.Xa[t], e.p, G0, K);
 #if SR_BWD_DIAG & 64
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const float tt = fmaf(-e.p, c.X0 + (float)t, G0); oG[t] = fmaf(tt, tt, K) * 0.001f; }   // timing experiment: no v_exp
+    for (int t = 0; t < 4; ++t) { const float tt = fmaf(-e.p, c.Xa[t], G0); oG[t] = fmaf(tt, tt, K) * 0.001f; }   // timing experiment: no v_exp
 #endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -357,7 +364,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
 #endif
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) alpha[t] = __builtin_amdgcn_fmed3f(oGc[t], 0.0f, kAlphaMax);
+    for (int t = 0; t < 4; ++t) alpha[t] = fminf(oGc[t], kAlphaMax);   // oGc >= 0
 #pragma unroll
 #if SR_BWD_DIAG & 64
     for (int t = 0; t < 4; ++t) ginv[t] = 1.0f + alpha[t];   // timing experiment: no v_rcp
@@ -404,8 +411,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
         // dL/dalpha_n = T_n (c_n . g) - behind_n / (1 - alpha_n); gradients pass through the 0.99 clamp, as upstream
         const float dLa = T[t] * cgv[t] - ginv[t] * behind;
         const float g1 = oGc[t] * dLa;   // the six geometric sums carry the factor `opacity` (k_preprocess_backward)
-        const float X = c.X0 + ((float)t - 7.5f);   // wave-uniform
-        a0 += g1; a1 = fmaf(g1, X, a1); a2 = fmaf(g1, X * X, a2);
+        a0 += g1; a1 = fmaf(g1, c.Xc[t], a1); a2 = fmaf(g1, c.Xc2[t], a2);
         br = fmaf(wgt[t], c.gR[t], br); bg = fmaf(wgt[t], c.gG[t], bg); bb = fmaf(wgt[t], c.gB[t], bb);
         if (HAS_D) bd = fmaf(wgt[t], c.gD[t], bd);
     }
@@ -553,13 +559,21 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 first_of[blk] = len;
                 len += (uint32_t)__popc(s_mask[par][q][blk]);
             }
-            uint32_t run = 0u, my_base = 0u;
+            // run bases = exclusive prefix of the run lengths over the sixteen quads (a row scan).  When the total fits the
+            // slot buffer -- the usual case -- that is all; otherwise the quads are partitioned greedily into passes
+            // (sixteen scalar steps: ~160 instructions that every chunk used to pay)
+            const uint32_t incl = row_scan_add_u32(len);
+            uint32_t my_base = incl - len;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+            if (total > (uint32_t)kCap) {   // uniform
+                uint32_t run = 0u;
 #pragma unroll
-            for (int qq = 0; qq < 16; ++qq) {   // greedy partition into passes; values are wave-uniform (readlane)
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)len, qq);
-                if (run + pq > (uint32_t)kCap) { pass_starts |= 1u << qq; run = 0u; }
-                my_base = q == qq ? run : my_base;
-                run += pq;
+                for (int qq = 0; qq < 16; ++qq) {   // values are wave-uniform (readlane)
+                    const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)len, qq);
+                    if (run + pq > (uint32_t)kCap) { pass_starts |= 1u << qq; run = 0u; }
+                    my_base = q == qq ? run : my_base;
+                    run += pq;
+                }
             }
             if (lane < 16) {   // all four wavefronts write the same values; each reads back only its own writes
                 s_qlen[par][q] = len; s_qbase[par][q] = my_base;
@@ -641,26 +655,29 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                 QuadCtx c;
                 float ST[4], SB[4];
                 c.Y = (float)(4 * qy + k);
-                c.X0 = (float)(4 * qx);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {   // gfx950 has no scalar float arithmetic: three scalar loads from a constant table
+                    c.Xa[t] = kColumn[0][4 * qx + t]; c.Xc[t] = kColumn[1][4 * qx + t]; c.Xc2[t] = kColumn[2][4 * qx + t];
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float4 a = s_pixA[prow + t], cb = s_pixB[prow + t];
                     c.gR[t] = a.x; c.gG[t] = a.y; c.gB[t] = a.z; c.gD[t] = a.w;
                     c.gA[t] = cb.x; c.last[t] = __float_as_int(cb.y); ST[t] = cb.z; SB[t] = cb.w;
                 }
-                // Two buckets per iteration, UP then DOWN: independent except for the carries, so their instruction streams
-                // interleave.  The slots of the next iteration are read while this one computes.
+                // Two buckets per iteration, UP then DOWN (their carries meet in the lanes where they are produced).  The records
+                // are read where they are used: reading the next iteration's a round ahead (rounds 2-3) cost 24 register
+                // copies per iteration for the hand-over -- 65 VALU cycles of an issue-bound loop -- to hide an LDS latency that
+                // the SIMD's other wavefronts cover anyway.
                 const int last_bucket = ((len - 1) >> 4) << 4;   // first entry of the quad's last bucket
                 auto slot_of = [&](int i, bool up) { return s_slot + kF * (base + min(i, last_bucket) + (up ? nl : 15 - nl)); };
                 int i0 = 0;
-                float* sa = slot_of(0, true);
-                float* sb = slot_of(kBucket, false);
-                SlotIn ea = slot_get_record<HAS_D>(sa), eb = slot_get_record<HAS_D>(sb);
 #pragma unroll 1
                 for (; i0 + kBucket < len; i0 += 2 * kBucket) {
-                    float* sa_n = slot_of(i0 + 2 * kBucket, true);
-                    float* sb_n = slot_of(i0 + 3 * kBucket, false);
-                    const SlotIn na = slot_get_record<HAS_D>(sa_n), nb = slot_get_record<HAS_D>(sb_n);
+                    float* sa = slot_of(i0, true);
+                    float* sb = slot_of(i0 + kBucket, false);
+                    const SlotIn ea = slot_get_record<HAS_D>(sa);
+                    SlotIn eb = slot_get_record<HAS_D>(sb);
                     const bool vb = i0 + kBucket + (15 - nl) < len;   // bucket A is full
                     slot_mask_invalid(eb, vb);
 #ifdef SR_BWD_STATS
@@ -670,11 +687,11 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
                     const BucketSums Db = replay_bucket<false, HAS_D>(c, eb, ST, SB, lane);
                     slot_put_sums(sa, k, Da);
                     if (vb) slot_put_sums(sb, k, Db);
-                    sa = sa_n; sb = sb_n;
-                    ea = na; eb = nb;
                 }
                 const bool tail = i0 < len;   // a last single bucket (UP): its carries end in lane 15, otherwise they are in lane 0
                 if (tail) {
+                    float* sa = slot_of(i0, true);
+                    SlotIn ea = slot_get_record<HAS_D>(sa);
                     const bool va = i0 + nl < len;
                     slot_mask_invalid(ea, va);
 #ifdef SR_BWD_STATS
