@@ -532,11 +532,12 @@ k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image
         {   // one ballot per quad (its halves are the wavefront's two blocks); lane q (< 16) collects quad q's mask
             uint32_t mlo = 0u, mhi = 0u;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 16; ++q) {   // v_writelane: the scalar ballot halves go straight into lane q (one instruction each)
                 const uint64_t bal = __builtin_amdgcn_ballot_w64(((qm >> q) & 1u) != 0u);
-                const bool mine = lane == q;
-                mlo = mine ? (uint32_t)bal : mlo;
-                mhi = mine ? (uint32_t)(bal >> 32) : mhi;
+                // (inline assembly: no builtin; s_nop 3 = the wait states a v_writelane needs behind the VALU write of the scalar
+                // it reads -- the ballot's v_cmp --, which the hazard recogniser does not see inside an asm statement)
+                asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                    : "+v"(mlo), "+v"(mhi) : "s"((uint32_t)bal), "s"((uint32_t)(bal >> 32)), "n"(q));
             }
             if (lane < 16) { s_mask[par][lane][2 * wave] = mlo; s_mask[par][lane][2 * wave + 1] = mhi; }
         }
