@@ -46,6 +46,8 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
     const int base_chunk = (int)blockIdx.x / ch.slices, slice = (int)blockIdx.x % ch.slices;
     const int sb0 = base_chunk * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
+    // (Requesting the inputs of four sub-batches at a time, as k_emit does, was measured here in round 4: the scan stage went
+    // from 0.0489 to 0.0516 ms -- 83 instead of 56 registers -- where the scatter gained 2 us.)
     for (int sb = sb0; sb < sb1; ++sb) {
         const int idx = sb * kBlock + threadIdx.x;
         uint32_t touched = 0;
@@ -234,37 +236,58 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         const int n_tiles = v.gx * v.gy;
         for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + sbase[t] + row[t];
     }
-    for (int sb = sb0; sb < sb1; ++sb) {
-        const int idx = sb * kBlock + threadIdx.x;
-        uint32_t touched = 0;
-        ushort4 rect = make_ushort4(0, 0, 0, 0);
-        uint32_t dbits = 0;
-        float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = r0;
-        if (idx < N) {
-            touched = g.touched[idx];
-            rect = g.rect[idx];
-            dbits = g.depth_bits[idx];  // view depth > 0.2: float bits sort as integers
-            if (touched >= kCullMinTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; }
+    // The chunk's sub-batches are walked one after the other (each needs the workgroup's scan and its LDS tables), but their
+    // per-splat inputs are requested kAhead sub-batches at a time: a workgroup is a serial chain of sub-batches with a memory
+    // round trip per link otherwise (0.0317 -> 0.0298 ms at the headline)
+    constexpr int kAhead = 4;
+    for (int sbg = sb0; sbg < sb1; sbg += kAhead) {
+        uint32_t touched_a[kAhead], dbits_a[kAhead], base_a[kAhead];
+        ushort4 rect_a[kAhead];
+        float4 r0_a[kAhead], r1_a[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int idx = (sbg + u) * kBlock + threadIdx.x;
+            touched_a[u] = 0; dbits_a[u] = 0; base_a[u] = 0; rect_a[u] = make_ushort4(0, 0, 0, 0);
+            if (sbg + u < sb1) {
+                base_a[u] = g.block_offsets[sbg + u];
+                if (idx < N) {
+                    touched_a[u] = g.touched[idx];
+                    rect_a[u] = g.rect[idx];
+                    dbits_a[u] = g.depth_bits[idx];  // view depth > 0.2: float bits sort as integers
+                }
+            }
         }
-        uint32_t total;
-        const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // leading barrier protects LDS reuse
-        const uint32_t base = g.block_offsets[sb];
-        if (idx < N) g.offsets[idx] = base + excl;
-        s_off[threadIdx.x] = excl;
-        s_rect[threadIdx.x] = rect;
-        s_depth[threadIdx.x] = dbits;
-        tile_test_prepare(r0, r1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
-        if (threadIdx.x == 0) s_off[kBlock] = total;
-        __syncthreads();
-        const uint32_t first_splat = (uint32_t)sb * kBlock;
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
-            b.reached[base + local_inst] = 0;   // instance order: consecutive threads, consecutive bytes
-            if (rect_tiles >= kCullMinTiles && !tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) return;   // as in the count pass
-            uint32_t slot;
-            if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
-            else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
-            b.ent[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(first_splat + (uint32_t)e);
-        }, slice, slices);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int idx = (sbg + u) * kBlock + threadIdx.x;
+            r0_a[u] = make_float4(0.f, 0.f, -1.f, 0.f); r1_a[u] = r0_a[u];
+            if (touched_a[u] >= kCullMinTiles) { r0_a[u] = g.rec[4 * (size_t)idx]; r1_a[u] = g.rec[4 * (size_t)idx + 1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int sb = sbg + u;
+            if (sb >= sb1) break;   // uniform
+            const int idx = sb * kBlock + threadIdx.x;
+            uint32_t total;
+            const uint32_t excl = block_exclusive_scan(touched_a[u], s_scan, total);  // leading barrier protects LDS reuse
+            const uint32_t base = base_a[u];
+            if (idx < N) g.offsets[idx] = base + excl;
+            s_off[threadIdx.x] = excl;
+            s_rect[threadIdx.x] = rect_a[u];
+            s_depth[threadIdx.x] = dbits_a[u];
+            tile_test_prepare(r0_a[u], r1_a[u], s_r0[threadIdx.x], s_r1[threadIdx.x]);
+            if (threadIdx.x == 0) s_off[kBlock] = total;
+            __syncthreads();
+            const uint32_t first_splat = (uint32_t)sb * kBlock;
+            for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
+                b.reached[base + local_inst] = 0;   // instance order: consecutive threads, consecutive bytes
+                if (rect_tiles >= kCullMinTiles && !tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) return;   // as in the count pass
+                uint32_t slot;
+                if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
+                else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
+                b.ent[slot] = ((uint64_t)s_depth[e] << 32) | (uint64_t)(first_splat + (uint32_t)e);
+            }, slice, slices);
+        }
     }
 }
 
