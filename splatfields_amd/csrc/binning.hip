@@ -187,6 +187,20 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
             s_hist[4 * lane + 3] = excl + c0 + c1 + c2;
         }
         __syncthreads();
+        // How many slots at the head of tile_order can hold a list longer than 2048 / 4096 / 8192 entries (all tiles of the
+        // classes down to the one such a length falls into): the long-list sort classes walk only those slots instead of
+        // spinning up a workgroup per tile to find out that the tile is not theirs (13.8 us per launch at the headline, on the
+        // views that have a single list beyond 2048 entries).
+        if (tid < 3) {
+            const uint32_t lo = 2048u << tid;   // lists longer than lo
+            uint32_t cand = 0u;
+            if (longest > lo) {
+                const uint32_t cls = 255u - min(255u, (uint32_t)((float)(lo + 1u) * to_class));   // class of length lo + 1: longer lists have classes <= cls
+                cand = cls >= 255u ? (uint32_t)n : s_hist[cls + 1u];   // exclusive prefix = tiles in classes 0 .. cls
+            }
+            g.total[4 + tid] = cand;
+        }
+        __syncthreads();
         for (int i = tid; i < n; i += 1024) {
             const uint32_t len = dst[i + 1] - dst[i];
             g.tile_order[atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u)] = (uint32_t)i;
@@ -546,7 +560,8 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_merge(const Geom g, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
     if (g.total[0] > b.capacity) return;
-    for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
+    const uint32_t limit = min((uint32_t)n_tiles, g.total[LO == 2048 ? 4 : 5]);   // slots that can hold a list longer than LO
+    for (uint32_t slot = blockIdx.x; slot < limit; slot += gridDim.x) {
         const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
@@ -566,7 +581,8 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint64_t* run_key = reinterpret_cast<uint64_t*>(s_dyn);
     if (g.total[0] > b.capacity) return;
-    for (uint32_t slot = blockIdx.x; slot < (uint32_t)n_tiles; slot += gridDim.x) {
+    const uint32_t limit = min((uint32_t)n_tiles, g.total[6]);   // slots that can hold a list longer than 8192 entries
+    for (uint32_t slot = blockIdx.x; slot < limit; slot += gridDim.x) {
         const uint32_t tile = g.tile_order[slot];  // longest lists first
         const uint32_t start = g.tile_start[tile];
         const uint32_t n = g.tile_start[tile + 1] - start;
@@ -613,12 +629,13 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<2048, 4096, 1024>), 2, (int)lds(4096, 1024));
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_merge<4096, 8192, 1024>), 3, (int)lds(8192, 1024));
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), 4, (int)lds(8192, 1024));
-    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(tiles), dim3(1024), lds(4096, 1024), st, g, b, tiles);
+    // the long classes walk the head of tile_order (Geom::total[4..6] slots) with a grid of at most two workgroups per CU
+    const int long_grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(long_grid), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
-    // dense scenes put many tiles in this class too: one workgroup per tile (the launch is skipped when no list is this long)
-    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(tiles), dim3(1024), lds(8192, 1024), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(long_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 8192) return;
-    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(tiles), dim3(1024), lds(8192, 1024), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(long_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
 }
 
 }  // namespace sr

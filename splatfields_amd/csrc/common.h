@@ -53,7 +53,7 @@ struct Geom {
     uint32_t* tile_start;    // [tiles+1]
     uint32_t* tile_cursor;   // [tiles]
     uint32_t* tile_order;    // [tiles] tiles by decreasing list length (coarse classes): launch order of the blend kernels
-    uint32_t* total;         // [0] number of instances, [1] longest tile list
+    uint32_t* total;         // [0] number of instances, [1] longest tile list, [4..6] slots of tile_order that can hold lists > 2048 / 4096 / 8192
     // written by the forward blend, read by the backward kernels:
     uint32_t* tile_qlast;    // [tiles][16] per 4x4-pixel quad (row-major in the tile): list entries in front of the stop of its
                              //     last pixel (max over the quad's pixels of n_contrib); the backward replays [0, max over quads)
@@ -148,7 +148,7 @@ inline size_t carve_geom(void* base, int N, int H, int W, Geom* g) {
     t.flags = c.take<uint8_t>(n);
     t.block_sums = c.take<uint32_t>(nb); t.block_offsets = c.take<uint32_t>(nb);
     t.tile_count = c.take<uint32_t>(tiles); t.tile_start = c.take<uint32_t>(tiles + 1);
-    t.tile_cursor = c.take<uint32_t>(tiles); t.tile_order = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(4);
+    t.tile_cursor = c.take<uint32_t>(tiles); t.tile_order = c.take<uint32_t>(tiles); t.total = c.take<uint32_t>(8);
     t.tile_qlast = c.take<uint32_t>(16 * tiles);
     t.cnt = t.segtot = t.segbase = nullptr;
     if (tiles <= (size_t)kMaxMatrixTiles) {
