@@ -149,8 +149,8 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
  * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes.
  * `instances_rendered`: the instance count the forward reported for these buffers (*instances_out), or -1 if the caller did
  * not keep it.  It only selects between the two backward blend kernels, which produce the same gradient slots: small
- * footprints (fewer than SR_BWD_WAVE_KERNEL_ABOVE instances per splat) replay on the entry-per-lane MFMA kernel
- * (blend_bwd.hip), large footprints on the pixel-per-lane kernel (render.hip); unknown = the former.
+ * footprints (fewer than SR_BWD_WAVE_KERNEL_ABOVE instances per splat) replay on the entry-per-lane kernel (quad buckets, DPP
+ * scans: blend_bwd.hip), large footprints on the pixel-per-lane kernel (render.hip); unknown = the former.
  * `binning` is NOT const: the backward blend sets, inside it, one `reached` byte per tile-splat instance it wrote a gradient
  * slot for (the forward's scatter cleared them), and the per-splat reduction reads them back.  Consequences for callers:
  * ONE backward at a time per set of forward buffers (two concurrent backwards on the same buffers -- different streams or
@@ -180,7 +180,7 @@ int sr_backward_splats(const SrView* view, const SrSplats* splats, const void* g
 
 /* Pins the backward blend kernel for A/B measurements and for the test that compares the two: 0 = chosen per launch by the
  * footprint (default), 1 = pixel-per-lane kernel, 2 = entry-per-lane kernel.  The initial value comes from the environment
- * variable SPLATRASTER_BWD ("wave" = 1, "mfma" = 2), read once when the library is loaded.  Process-wide; returns the
+ * variable SPLATRASTER_BWD ("wave" = 1, "quads" = 2), read once when the library is loaded.  Process-wide; returns the
  * previous setting, or -1 for an unknown value (nothing changes). */
 int sr_set_backward_kernel(int which);
 

@@ -79,7 +79,7 @@ int get_host_sync(HostSync** out) {
 // 0 = choose the backward blend kernel by footprint, 1 = pixel-per-lane, 2 = entry-per-lane (sr_set_backward_kernel)
 std::atomic<int> g_bwd_kernel{[] {
     const char* sel = getenv("SPLATRASTER_BWD");
-    return !sel ? 0 : (std::string(sel) == "wave" ? 1 : (std::string(sel) == "mfma" ? 2 : 0));
+    return !sel ? 0 : (std::string(sel) == "wave" ? 1 : ((std::string(sel) == "quads" || std::string(sel) == "mfma") ? 2 : 0));
 }()};
 
 #define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
@@ -278,12 +278,12 @@ int backward_impl(int what, const SrView* view, const SrSplats* splats, const vo
         // Two kernels, one slot format.  Entry-per-lane (MFMA moment reduction) wins while a splat reaches few pixels of a tile
         // (measured on MI355X, 800x800: 0.286 vs 0.370 ms at 2.3 instances per splat, 0.207 vs 0.215 at 4.6); pixel-per-lane
         // (wave butterflies) wins once most lanes of an 8x8 sub-tile are inside the footprint (0.192 vs 0.203 at 7.4, 0.182 vs
-        // 0.203 at 15).  SPLATRASTER_BWD=wave|mfma pins one of them (A/B measurements).
+        // 0.203 at 15).  SPLATRASTER_BWD=wave|quads pins one of them (A/B measurements; "mfma", the name of rounds 2-3, is accepted for "quads").
         const int pinned = g_bwd_kernel.load(std::memory_order_relaxed);   // sr_set_backward_kernel / SPLATRASTER_BWD at load time
         const bool dense = instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N;
         const bool wave_kernel = pinned ? pinned == 1 : dense;
         if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
-        else sr::launch_render_backward_mfma(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
+        else sr::launch_render_backward_quads(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
     }
     if (what & 1) SR_TRY(after_launch(view, st, "render_backward"));
     if (what & 2) {

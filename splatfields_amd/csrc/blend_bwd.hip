@@ -1,4 +1,4 @@
-// Backward of the alpha compositing for gfx950 -- "entry-per-lane" formulation with MFMA moment reduction.
+// Backward of the alpha compositing for gfx950 -- "entry-per-lane" formulation over 4x4-pixel quads.
 //
 // Semantics: SURVEY.md Appendix A "Backward blend" (the renderCUDA backward of the published rasterizer reached from
 // reference gaussian_renderer/__init__.py:94-102 through train.py:252), identical to what render.hip's forward blended.
@@ -12,17 +12,18 @@
 //     entries in lanes n = lane & 15 and the quad's four pixel rows in k = lane >> 4; it walks the quad's four pixel
 //     columns t = 0..3, so every step evaluates 16 entries x 4 pixels.
 //   * transmittance / "colour behind" recurrences along the list become two 16-lane prefix scans per step (DPP row
-//     shifts, carry between buckets in lane 15) -- no per-pixel serial loop, no early-exit divergence.
-//   * the ten sums over pixels are a dense contraction with operands SHARED by all entries of the quad:
-//       [M0 MX MY MXX MXY MYY](entry) = W(6 x 16 pixels)  . g1(16 pixels x entry)      (pixel monomials 1, X, Y, X^2, XY, Y^2)
-//       [dr dg db dd](entry)          = G(4 x 16 pixels)  . wgt(16 pixels x entry)     (upstream colour/depth gradients)
-//     = two v_mfma_f32_16x16x4_f32 per step (exact fp32 fma chains), accumulated over the four steps: no butterflies,
-//     no products with dx, dy in the VALU stream.  Moments are taken about the TILE centre and shifted to the splat
-//     centre once per (tile, entry) when the quads' partial sums are combined.
+//     shifts, carry between buckets in lane 15) -- no per-pixel serial loop, no early-exit divergence.  The four columns are
+//     computed stage by stage side by side (replay_bucket): four independent chains fill each other's dependent-issue gaps.
+//   * the ten sums over pixels: seven per-lane accumulators over the four columns (moments of g1 in X, colour / depth sums of
+//     the weights), the row's Y applied per lane, then eight swap-adds (v_permlane32_swap / v_permlane16_swap) over the four
+//     rows.  Moments are taken about the TILE centre and shifted to the splat centre once per (tile, entry) when the quads'
+//     partial sums are combined.  (Rounds 2-3 contracted them with two v_mfma_f32_16x16x4_f32 per column.  Round 4 measured
+//     -- tools/mfma_valu_coissue.hip -- that on gfx950 the fp32 MFMA and the SIMD's VALU instructions do not overlap: their
+//     times ADD, an fp32 MFMA is 32 cycles of the vector ALUs; eight per bucket cost more than the VALU form of the sums.)
 //   * the quads' entry lists are built per chunk of the tile list from the quad-reach masks the forward left per list entry
-//     (exact-support test, quadmask.h), bucketed with ballots + prefix counts; a slot of the LDS scratch first carries the entry's record to the wavefront that
-//     owns the quad and then carries the 10 sums back.  Everything is summed in a fixed order: bit-reproducible,
-//     no floating-point atomics (as before).
+//     (exact-support test, quadmask.h), bucketed with ballots + prefix counts; a slot of the LDS scratch first carries the
+//     entry's record to the wavefront that owns the quad and then carries the 10 sums back.  Everything is summed in a fixed
+//     order: bit-reproducible, no floating-point atomics (as before).
 #include "kernels.h"
 
 namespace sr {
@@ -430,7 +431,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
 // arguments/__init__.py:166,168): the depth channel is then compiled out of the replay and of the LDS slots.
 template <bool HAS_D>
 __global__ void __launch_bounds__(kBlock, HAS_D ? 3 : SR_BWD_WAVES_PER_SIMD)   // with the depth channel the 48-byte slots allow three per CU anyway
-k_render_backward_mfma(const ViewK v, const Geom g, const Binning b, const Image im, const float* __restrict__ dL_dcolor,
+k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Image im, const float* __restrict__ dL_dcolor,
                        const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha, float* __restrict__ slots) {
     constexpr int kF = SlotFmt<HAS_D>::kF;
     constexpr int kCap = SlotCap<HAS_D>::kCap;
@@ -779,13 +780,13 @@ int backward_stats(unsigned long long* out8, int reset) {   // out8: 16 entries
 #endif
 }
 
-void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+void launch_render_backward_quads(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                  float* slots, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
-    if (dL_ddepth) hipLaunchKernelGGL(k_render_backward_mfma<true>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
-    else hipLaunchKernelGGL(k_render_backward_mfma<false>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    if (dL_ddepth) hipLaunchKernelGGL(k_render_backward_quads<true>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
+    else hipLaunchKernelGGL(k_render_backward_quads<false>, dim3(tiles), dim3(kBlock), 0, st, v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots);
 }
 
 }  // namespace sr

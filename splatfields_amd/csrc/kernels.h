@@ -38,7 +38,7 @@ void launch_render_backward(const ViewK& v, const Geom& g, const Binning& b, con
                             const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                             float* slots, hipStream_t st);
 // blend_bwd.hip
-void launch_render_backward_mfma(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
+void launch_render_backward_quads(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                  float* slots, hipStream_t st);
 

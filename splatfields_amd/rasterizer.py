@@ -60,14 +60,14 @@ def set_depth_gradient(enabled: bool) -> bool:
 def depth_gradient_enabled() -> bool:
     return _DEPTH_GRADIENT
 
-_BWD_KERNELS = {None: 0, "auto": 0, "wave": 1, "mfma": 2}
+_BWD_KERNELS = {None: 0, "auto": 0, "wave": 1, "quads": 2, "mfma": 2}   # "mfma": the name rounds 2-3 gave the entry-per-lane kernel
 
 
 def set_backward_kernel(which) -> str:
     """Pin the backward blend kernel (A/B measurements, the test that compares the two): None / "auto" = chosen per launch by
-    the footprint, "wave" = pixel-per-lane, "mfma" = entry-per-lane.  Returns the previous setting."""
+    the footprint, "wave" = pixel-per-lane, "quads" = entry-per-lane (quad buckets).  Returns the previous setting."""
     prev = _lib.load().sr_set_backward_kernel(_BWD_KERNELS[which])
-    return {0: "auto", 1: "wave", 2: "mfma"}[prev]
+    return {0: "auto", 1: "wave", 2: "quads"}[prev]
 
 
 # Per-device estimate of the instance count used to size the binning buffer BEFORE the count is known, so that

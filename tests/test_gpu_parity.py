@@ -226,14 +226,14 @@ def test_image_with_exactly_16384_tiles(hip_device):
 
 @pytest.mark.parametrize("n,w,h,scale", [(6000, 208, 160, None), (3000, 160, 128, 0.08)])
 def test_both_backward_blend_kernels_agree(hip_device, n, w, h, scale):
-    """sr_backward picks the entry-per-lane (MFMA) or the pixel-per-lane (butterfly) kernel by the mean footprint; both write
+    """sr_backward picks the entry-per-lane (quad buckets) or the pixel-per-lane (butterfly) kernel by the mean footprint; both write
     the same gradient slots.  Pinned through sr_set_backward_kernel they must agree to fp32 round-off (different summation order)
     and each must match the oracle, on a small-footprint and on a large-footprint scene."""
     sp, cam, st, grads = make_scene(n, w, h, mean_scale=scale, view=2)
     res = {}
     from splatfields_amd.rasterizer import set_backward_kernel
     try:
-        for kernel in ("mfma", "wave"):
+        for kernel in ("quads", "wave"):
             set_backward_kernel(kernel)
             _, res[kernel] = run_hip(sp, st, grads, hip_device)
     finally:
@@ -241,9 +241,9 @@ def test_both_backward_blend_kernels_agree(hip_device, n, w, h, scale):
     _, auto = run_hip(sp, st, grads, hip_device)
     _, gr = O.fwd_bwd(sp, st, *grads, use_sh=True, dtype=torch.float64)
     for k in gr:
-        assert grad_error(res["mfma"][k], res["wave"][k]) <= 5e-5, (k, grad_error(res["mfma"][k], res["wave"][k]))
-        assert grad_error(res["mfma"][k], gr[k]) <= GRAD_TOL64 and grad_error(res["wave"][k], gr[k]) <= GRAD_TOL64, k
-        assert torch.equal(auto[k], res["mfma"][k]) or torch.equal(auto[k], res["wave"][k]), k   # the automatic choice is one of them
+        assert grad_error(res["quads"][k], res["wave"][k]) <= 5e-5, (k, grad_error(res["quads"][k], res["wave"][k]))
+        assert grad_error(res["quads"][k], gr[k]) <= GRAD_TOL64 and grad_error(res["wave"][k], gr[k]) <= GRAD_TOL64, k
+        assert torch.equal(auto[k], res["quads"][k]) or torch.equal(auto[k], res["wave"][k]), k   # the automatic choice is one of them
 
 
 def test_depth_gradient_switch(hip_device):

@@ -30,14 +30,14 @@ def main():
         sp, cam, st, grads = make_scene(n, w, h, mean_scale=scale, view=rnd.randint(0, 7), bg=bg, sh_degree=rnd.randint(0, 3),
                                         seed=1000 + it)
         res = {}
-        for kernel in ("mfma", "wave", "mfma"):
+        for kernel in ("quads", "wave", "quads"):
             set_backward_kernel(kernel)
             _, g = run_hip(sp, st, grads, dev, use_sh=use_sh, with_depth=wd, with_alpha=wa)
             res.setdefault(kernel, []).append(g)
         set_backward_kernel(None)
-        e = max(grad_error(res["mfma"][0][k], res["wave"][0][k]) for k in res["wave"][0])
-        repro = all(torch.equal(res["mfma"][0][k], res["mfma"][1][k]) for k in res["wave"][0])
-        finite = all(torch.isfinite(v).all() for v in res["mfma"][0].values())
+        e = max(grad_error(res["quads"][0][k], res["wave"][0][k]) for k in res["wave"][0])
+        repro = all(torch.equal(res["quads"][0][k], res["quads"][1][k]) for k in res["wave"][0])
+        finite = all(torch.isfinite(v).all() for v in res["quads"][0].values())
         worst = max(worst, e)
         flag = "" if (e <= 2e-4 and repro and finite) else "  <-- CHECK"
         bad += bool(flag)
