@@ -68,7 +68,8 @@ def test_roofline_valu_is_reproducible_from_the_committed_counters():
         assert 0.9 < sh["parked"] + sh["issue_stalled"] + sh["issuing"] < 1.1   # the three buckets partition the wave cycles
         flop = {"render_forward": 30.0, "render_backward": 90.0}[stage]
         assert abs(s["useful_flop_frac"] - 36.9e6 * flop / (stage_ms[stage] * 1e-3) / 157.3e12) < 1e-12
-    assert r["render_backward"]["mfma_insts_per_launch"] > 0 and r["render_forward"]["mfma_insts_per_launch"] == 0
+    # since round 4 neither blend kernel issues an MFMA (fp32 MFMAs and VALU instructions do not overlap on a gfx950 SIMD)
+    assert r["render_backward"]["mfma_insts_per_launch"] == 0 and r["render_forward"]["mfma_insts_per_launch"] == 0
     # another workload has no recorded counters
     assert bench.valu_roofline(dict(wl, splats=123), {}, check_hash=False) is None
 
