@@ -403,6 +403,15 @@ int sr_debug_layout(int n_splats, int height, int width, long long instances, si
  * Synchronises the device; reset != 0 clears the counters afterwards. */
 int sr_debug_backward_stats(unsigned long long* out16, int reset);
 
+/* debug = true (SrView.debug): every stage is followed by a stream synchronisation + error check, and a FAILED stage writes
+ * the call's arguments to snapshot_fw.dump / snapshot_bw.dump in the working directory before the error is returned -- what
+ * [EXT] does with `debug` set (its snapshot_fw.dump / snapshot_bw.dump; reference gaussian_renderer/__init__.py:71 passes
+ * pipe.debug).  Format: "SRSNAP1\0", failing stage [32], then records {name[16], uint64 bytes, payload}: view scalars,
+ * count, camera arrays, every per-splat input that was passed, for the backward the upstream gradients (a record whose
+ * device-to-host copy fails has 0 bytes).  sr_debug_snapshot runs that path for given arguments without a failure (tests). */
+int sr_debug_snapshot(const SrView* view, const SrSplats* splats, const float* dL_dcolor, const float* dL_ddepth,
+                      const float* dL_dalpha, int backward);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; off by default, adds two event records per launch when on).
  * sr_profile_collect synchronises the recorded events, ADDS the elapsed milliseconds and launch counts

@@ -84,10 +84,71 @@ std::atomic<int> g_bwd_kernel{[] {
 
 #define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
+// ---- debug = true: input snapshot on a failed launch ------------------------------------------------------------------
+// [EXT] with `debug` set synchronises after every kernel and, when one fails, dumps the call's arguments to
+// snapshot_fw.dump / snapshot_bw.dump in the working directory before it re-raises (SURVEY.md section 8b "Error
+// conventions").  Same here.  File: "SRSNAP1\0", the failing stage (32 bytes), then records {name[16], uint64 bytes, payload}:
+// "view" (SrView scalars: height, width, tanfovx, tanfovy, scale_modifier, sh_degree, sh_coeffs, prefiltered as 8 x 4 bytes),
+// "count" (int32), the four camera arrays and every per-splat input that was passed (copied back from the device; a record
+// whose copy fails -- the device may be gone after a fault -- has bytes = 0), for the backward also the upstream gradients.
+struct CallContext { const SrView* view = nullptr; const SrSplats* splats = nullptr; const char* file = nullptr;
+                     const float* dL_dcolor = nullptr; const float* dL_ddepth = nullptr; const float* dL_dalpha = nullptr; };
+thread_local CallContext g_call;
+
+void dump_record(FILE* f, const char* name, const void* dev, size_t bytes, bool on_device) {
+    char tag[16] = {0};
+    std::strncpy(tag, name, 15);
+    std::vector<char> host;
+    uint64_t n = 0;
+    if (dev && bytes) {
+        host.resize(bytes);
+        if (!on_device) { std::memcpy(host.data(), dev, bytes); n = bytes; }
+        else if (hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost) == hipSuccess) n = bytes;
+        else (void)hipGetLastError();
+    }
+    std::fwrite(tag, 1, 16, f); std::fwrite(&n, 8, 1, f);
+    if (n) std::fwrite(host.data(), 1, (size_t)n, f);
+}
+
+void dump_snapshot(const char* stage) {
+    const CallContext& c = g_call;
+    if (!c.view || !c.splats || !c.file) return;
+    FILE* f = std::fopen(c.file, "wb");
+    if (!f) return;
+    char head[8] = {'S', 'R', 'S', 'N', 'A', 'P', '1', 0}, st[32] = {0};
+    std::strncpy(st, stage, 31);
+    std::fwrite(head, 1, 8, f); std::fwrite(st, 1, 32, f);
+    const SrView* v = c.view; const SrSplats* s = c.splats;
+    const int32_t vi[4] = {v->image_height, v->image_width, v->sh_degree, v->sh_coeffs};
+    const float vf[3] = {v->tanfovx, v->tanfovy, v->scale_modifier};
+    char vb[32]; std::memcpy(vb, vi, 16); std::memcpy(vb + 16, vf, 12); const int32_t pf = v->prefiltered; std::memcpy(vb + 28, &pf, 4);
+    dump_record(f, "view", vb, 32, false);
+    const int32_t n = s->count;
+    dump_record(f, "count", &n, 4, false);
+    dump_record(f, "viewmatrix", v->viewmatrix, 64, true); dump_record(f, "projmatrix", v->projmatrix, 64, true);
+    dump_record(f, "campos", v->campos, 12, true); dump_record(f, "bg", v->bg, 12, true);
+    const size_t N = (size_t)(n > 0 ? n : 0);
+    dump_record(f, "means3D", s->means3D, N * 12, true); dump_record(f, "opacities", s->opacities, N * 4, true);
+    dump_record(f, "scales", s->scales, N * 12, true); dump_record(f, "rotations", s->rotations, N * 16, true);
+    dump_record(f, "cov3D_precomp", s->cov3D_precomp, N * 24, true);
+    dump_record(f, "shs", s->shs, s->shs ? N * 12 * (size_t)(s->shs_rest ? 1 : v->sh_coeffs) : 0, true);
+    dump_record(f, "shs_rest", s->shs_rest, N * 12 * 15, true);
+    dump_record(f, "colors_precomp", s->colors_precomp, N * 12, true);
+    const size_t px = (size_t)v->image_height * v->image_width;
+    dump_record(f, "dL_dcolor", c.dL_dcolor, px * 12, true); dump_record(f, "dL_ddepth", c.dL_ddepth, px * 4, true);
+    dump_record(f, "dL_dalpha", c.dL_dalpha, px * 4, true);
+    std::fclose(f);
+}
+
 int after_launch(const SrView* view, hipStream_t st, const char* what) {
-    SR_TRY(check_hip(hipGetLastError(), what));
-    if (view && view->debug) SR_TRY(check_hip(hipStreamSynchronize(st), what));
-    return 0;
+    int rc = check_hip(hipGetLastError(), what);
+    if (!rc && view && view->debug) rc = check_hip(hipStreamSynchronize(st), what);
+    if (rc && view && view->debug) {
+        const std::string keep = g_last_error;
+        dump_snapshot(what);
+        g_last_error = keep + (g_call.file ? std::string(" (inputs written to ") + g_call.file + ")" : std::string());
+    }
+    return rc;
 }
 
 int validate(const SrView* view, const SrSplats* s) {
@@ -192,6 +253,7 @@ extern "C" {
 int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, int* radii,
                        long long* instances_out, void* hip_stream) {
     SR_TRY(validate(view, splats));
+    g_call = CallContext{view, splats, "snapshot_fw.dump"};
     if (!geom || !instances_out || (splats->count > 0 && !radii)) return fail("null geom/radii/instances_out");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const sr::ViewK v = make_view(view);
@@ -210,6 +272,7 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
                long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,
                long long* instances_out, void* hip_stream) {
     SR_TRY(validate(view, splats));
+    g_call = CallContext{view, splats, "snapshot_fw.dump"};
     if (!geom || !binning || !image || !out_color || !out_depth || !instances_out || (splats->count > 0 && !radii)) return fail("null buffer");
     if (binning_capacity < 0 || binning_capacity >= (1ll << 32)) return fail("binning capacity out of range");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -233,6 +296,7 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
                       long long instances, void* image, float* out_color, float* out_depth,
                       float* out_alpha, void* hip_stream) {
     SR_TRY(validate(view, splats));
+    g_call = CallContext{view, splats, "snapshot_fw.dump"};
     if (!geom || !binning || !image || !out_color || !out_depth) return fail("null buffer");
     if (instances < 0 || instances >= (1ll << 32)) return fail("instance count out of range");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
@@ -252,6 +316,7 @@ int backward_impl(int what, const SrView* view, const SrSplats* splats, const vo
                   const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
                   const SrGrads* grads, int first, int count, void* hip_stream) {
     SR_TRY(validate(view, splats));
+    g_call = CallContext{view, splats, "snapshot_bw.dump", dL_dcolor, dL_ddepth, dL_dalpha};
     if (!geom || !binning || !image || !scratch) return fail("null buffer");
     if ((what & 1) && !dL_dcolor) return fail("null buffer");
     if ((what & 2) && !grads) return fail("null buffer");
@@ -519,6 +584,16 @@ int sr_debug_backward_stats(unsigned long long* out8, int reset) {
     if (!out8) return fail("null pointer in sr_debug_backward_stats");
     if (hipDeviceSynchronize() != hipSuccess) return fail("sr_debug_backward_stats: device synchronisation failed");
     return sr::backward_stats(out8, reset) ? fail("sr_debug_backward_stats: counter copy failed") : 0;
+}
+
+/* Test hook: runs the debug path of a failed launch for the given call arguments without breaking the device (writes
+ * snapshot_fw.dump / snapshot_bw.dump exactly as a failing stage with view->debug set would).  Returns 0. */
+int sr_debug_snapshot(const SrView* view, const SrSplats* splats, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                      int backward) {
+    if (!view || !splats) return fail("null view/splats");
+    g_call = CallContext{view, splats, backward ? "snapshot_bw.dump" : "snapshot_fw.dump", dL_dcolor, dL_ddepth, dL_dalpha};
+    dump_snapshot(backward ? "render_backward (test hook)" : "preprocess (test hook)");
+    return 0;
 }
 
 int sr_profile_enable(int on) { g_prof_on = on != 0; return 0; }

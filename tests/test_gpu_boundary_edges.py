@@ -141,3 +141,55 @@ def test_prefiltered_flag_changes_nothing(hip_device):
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
     assert (res[True][1][::3] == 0).all() and int((res[True][1] > 0).sum()) > 500
+
+
+def test_debug_snapshot_holds_the_call_arguments(hip_device, tmp_path, monkeypatch):
+    """`debug=True` (reference gaussian_renderer/__init__.py:71 passes pipe.debug): [EXT] synchronises after every kernel and,
+    when one fails, dumps the call's arguments to snapshot_fw.dump / snapshot_bw.dump before it re-raises.  The library does
+    the same (api.hip: after_launch -> dump_snapshot); the test hook runs that path without breaking the device, and the file
+    must hold exactly what was passed."""
+    import ctypes as C
+    import struct
+    import numpy as np
+    from splatfields_amd import _lib
+    from splatfields_amd.rasterizer import GaussianRasterizationSettings, _ViewPack, _splats_struct
+    lib = _lib.load()
+    dev = hip_device
+    monkeypatch.chdir(tmp_path)
+    sp, cam, st, grads = make_scene(777, 48, 32, view=2)
+    d = {k: v.to(dev).contiguous() for k, v in sp.items()}
+    rs = GaussianRasterizationSettings(image_height=32, image_width=48, tanfovx=st.tanfovx, tanfovy=st.tanfovy, bg=st.bg.to(dev),
+                                       scale_modifier=0.75, viewmatrix=st.viewmatrix.to(dev), projmatrix=st.projmatrix.to(dev),
+                                       sh_degree=2, campos=st.campos.to(dev), prefiltered=False, debug=True)
+    view = _ViewPack.get(rs, dev, 16)
+    splats = _splats_struct(777, d["means3D"], d["opacities"].reshape(-1), d["scales"], d["rotations"], None, d["shs"], None)
+    gi = grads[0].to(dev).contiguous()
+    assert lib.sr_debug_snapshot(C.byref(view.struct), C.byref(splats), C.c_void_p(gi.data_ptr()), None, None, 1) == 0
+    assert lib.sr_debug_snapshot(C.byref(view.struct), C.byref(splats), None, None, None, 0) == 0
+    for name, want_grad in (("snapshot_bw.dump", True), ("snapshot_fw.dump", False)):
+        raw = (tmp_path / name).read_bytes()
+        assert raw[:8] == b"SRSNAP1\0" and b"test hook" in raw[8:40]
+        recs, off = {}, 40
+        while off < len(raw):
+            tag = raw[off:off + 16].split(b"\0")[0].decode()
+            n, = struct.unpack_from("<Q", raw, off + 16)
+            recs[tag] = raw[off + 24:off + 24 + n]
+            off += 24 + n
+        h, w, deg, k = struct.unpack_from("<4i", recs["view"], 0)
+        tfx, tfy, sm = struct.unpack_from("<3f", recs["view"], 16)
+        assert (h, w, deg, k) == (32, 48, 2, 16) and abs(sm - 0.75) < 1e-7 and abs(tfx - st.tanfovx) < 1e-6 and abs(tfy - st.tanfovy) < 1e-6
+        assert struct.unpack("<i", recs["count"])[0] == 777
+        for key, ref in (("means3D", sp["means3D"]), ("opacities", sp["opacities"]), ("scales", sp["scales"]), ("rotations", sp["rotations"]),
+                         ("shs", sp["shs"]), ("viewmatrix", st.viewmatrix), ("projmatrix", st.projmatrix), ("campos", st.campos)):
+            got = np.frombuffer(recs[key], dtype=np.float32)
+            assert np.array_equal(got, ref.contiguous().numpy().reshape(-1)), key
+        assert len(recs["colors_precomp"]) == 0 and len(recs["cov3D_precomp"]) == 0 and len(recs["dL_ddepth"]) == 0
+        assert (len(recs["dL_dcolor"]) == 3 * 32 * 48 * 4) == want_grad
+        if want_grad:
+            assert np.array_equal(np.frombuffer(recs["dL_dcolor"], dtype=np.float32), grads[0].numpy().reshape(-1))
+    # and a debug render goes through (every stage synchronised and checked, nothing dumped, nothing raised)
+    from diff_gaussian_rasterization import GaussianRasterizer
+    (tmp_path / "snapshot_fw.dump").unlink()
+    color, radii, depth = GaussianRasterizer(rs)(means3D=d["means3D"], means2D=torch.zeros_like(d["means3D"]), opacities=d["opacities"],
+                                                 shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+    assert torch.isfinite(color).all() and not (tmp_path / "snapshot_fw.dump").exists()

@@ -302,6 +302,17 @@ def main():
 
         res[key + "_net_fwd_bwd_ms"] = timed(p_net_step, a.steps, 5)
         res[key + "_full_step_ms"] = timed(p_full_step, a.steps, 5)
+        # kernel launches of one full step (network forward + rasterizer + one backward), counted by the profiler
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                p_full_step()
+                torch.cuda.synchronize()
+            res[key + "_launches_per_step"] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+        except Exception as e:  # noqa: BLE001 -- a profiler that is not available must not cost the timings
+            res[key + "_launches_per_step"] = None
+            res[key + "_launches_error"] = repr(e)[:200]
         with torch.no_grad():
             res[key + "_net_forward_ms"] = timed(lambda: pnet(xyz, t_emb), a.steps, 5)
         res[key + "_net_parameters"] = sum(p.numel() for p in pnet.parameters())
@@ -330,6 +341,11 @@ def main():
     macs = sum(l.lin.weight.numel() for m in net.modules() if isinstance(m, GeneralMLP) for l in list(m.layers) + [m.out])
     res["mlp_macs_per_splat"] = macs + 2 * 48 * 48
     res["mlp_tflops_fwd_bwd_achieved"] = 3 * 2 * res["mlp_macs_per_splat"] * n / (res["net_fwd_bwd_ms"] * 1e-3) / 1e12
+    # the product step against the fp32 matrix roofline (forward + activation-gradient chain + weight gradients = 3 x the MACs;
+    # 157.3 TFLOP/s: on gfx950 the fp32 MFMA rate IS the fp32 vector rate, tools/mfma_valu_coissue.hip)
+    for key in ("product", "product_decoderfree"):
+        if res.get(key + "_full_step_ms"):
+            res[key + "_mfma_frac"] = 3 * 2 * res["mlp_macs_per_splat"] * n / (res[key + "_full_step_ms"] * 1e-3) / 157.3e12
     print(json.dumps(res))
 
 
