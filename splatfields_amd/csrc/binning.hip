@@ -48,17 +48,30 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     const int sb0 = base_chunk * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
     // (Requesting the inputs of four sub-batches at a time, as k_emit does, was measured here in round 4: the scan stage went
     // from 0.0489 to 0.0516 ms -- 83 instead of 56 registers -- where the scatter gained 2 us.)
+    // Rectangles of up to kDirectTiles tiles -- most of them when a splat's support is a few pixels -- are counted by their own
+    // thread (a few LDS atomics); only larger ones go through the workgroup's scan and the cooperative expansion (a
+    // binary search per instance), and a sub-batch without any skips both.
     for (int sb = sb0; sb < sb1; ++sb) {
         const int idx = sb * kBlock + threadIdx.x;
         uint32_t touched = 0;
         ushort4 rect = make_ushort4(0, 0, 0, 0);
         float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = r0;
         if (idx < N) { touched = g.touched[idx]; rect = g.rect[idx]; if (touched >= kCullMinTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; } }
+        float4 e0, e1;
+        tile_test_prepare(r0, r1, e0, e1);
+        const bool direct = ch.slices == 1 && touched <= kDirectTiles;
+        if (direct && touched > 0u) {
+            for (uint32_t ty = rect.y; ty < rect.w; ++ty)
+                for (uint32_t tx = rect.x; tx < rect.z; ++tx)
+                    if (touched < kCullMinTiles || tile_reached(e0, e1, tx, ty)) atomicAdd(&s_hist[ty * (uint32_t)v.gx + tx], 1u);  // LDS atomic
+        }
+        const uint32_t coop = direct ? 0u : touched;
+        if (!__syncthreads_or(coop != 0u)) continue;   // uniform: no large rectangle in this sub-batch (also protects s_off reuse)
         uint32_t total;
-        const uint32_t excl = block_exclusive_scan(touched, s_scan, total);  // starts with a barrier: protects s_off reuse
+        const uint32_t excl = block_exclusive_scan(coop, s_scan, total);
         s_off[threadIdx.x] = excl;
         s_rect[threadIdx.x] = rect;
-        tile_test_prepare(r0, r1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
+        s_r0[threadIdx.x] = e0; s_r1[threadIdx.x] = e1;
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
         for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
@@ -282,19 +295,40 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
             const int sb = sbg + u;
             if (sb >= sb1) break;   // uniform
             const int idx = sb * kBlock + threadIdx.x;
-            uint32_t total;
-            const uint32_t excl = block_exclusive_scan(touched_a[u], s_scan, total);  // leading barrier protects LDS reuse
+            // two prefixes over the sub-batch: all instances (their indices; `offsets`) and those of the rectangles that take the
+            // cooperative expansion -- the ones above kDirectTiles tiles (k_count_tiles makes the same split)
+            const bool direct = slices == 1u && touched_a[u] <= kDirectTiles;
+            const uint32_t coop = direct ? 0u : touched_a[u];
+            uint32_t total, coop_total;
+            uint32_t coop_excl;
+            const uint32_t excl = block_exclusive_scan2(touched_a[u], coop, s_scan, total, coop_excl, coop_total);  // leading barrier protects LDS reuse
             const uint32_t base = base_a[u];
             if (idx < N) g.offsets[idx] = base + excl;
-            s_off[threadIdx.x] = excl;
+            if (slice == 0u)
+                for (uint32_t i = threadIdx.x; i < total; i += kBlock) b.reached[base + i] = 0;   // consecutive threads, consecutive bytes
+            const uint32_t first_splat = (uint32_t)sb * kBlock;
+            float4 e0, e1;
+            tile_test_prepare(r0_a[u], r1_a[u], e0, e1);
+            if (direct && touched_a[u] > 0u) {
+                const uint64_t entry = ((uint64_t)dbits_a[u] << 32) | (uint64_t)(first_splat + threadIdx.x);
+                for (uint32_t ty = rect_a[u].y; ty < rect_a[u].w; ++ty)
+                    for (uint32_t tx = rect_a[u].x; tx < rect_a[u].z; ++tx) {
+                        if (touched_a[u] >= kCullMinTiles && !tile_reached(e0, e1, tx, ty)) continue;   // as in the count pass
+                        const uint32_t tile = ty * (uint32_t)v.gx + tx;
+                        uint32_t slot;
+                        if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
+                        else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);
+                        b.ent[slot] = entry;
+                    }
+            }
+            if (coop_total == 0u) continue;   // uniform
+            s_off[threadIdx.x] = coop_excl;
             s_rect[threadIdx.x] = rect_a[u];
             s_depth[threadIdx.x] = dbits_a[u];
-            tile_test_prepare(r0_a[u], r1_a[u], s_r0[threadIdx.x], s_r1[threadIdx.x]);
-            if (threadIdx.x == 0) s_off[kBlock] = total;
+            s_r0[threadIdx.x] = e0; s_r1[threadIdx.x] = e1;
+            if (threadIdx.x == 0) s_off[kBlock] = coop_total;
             __syncthreads();
-            const uint32_t first_splat = (uint32_t)sb * kBlock;
-            for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t local_inst, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
-                b.reached[base + local_inst] = 0;   // instance order: consecutive threads, consecutive bytes
+            for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
                 if (rect_tiles >= kCullMinTiles && !tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) return;   // as in the count pass
                 uint32_t slot;
                 if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
