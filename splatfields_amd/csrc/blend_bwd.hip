@@ -34,22 +34,26 @@ constexpr int kBucket = 16;                 // list entries per bucket = N of th
 constexpr int kBlkEntries = 32;             // granularity of a chunk of the tile list ("block" = half a wavefront's entries)
 constexpr int kBlocks = 8;                  // a chunk = up to 8 blocks = one list entry per thread
 // (quad, entry) slots per pass over a chunk.  A slot holds 10 floats (12 when the caller supplies a depth gradient, so that
-// the record's depth rides along).  LDS per workgroup: slots + 10 KB of tables, three workgroups per CU (53 KB each).
-// (Four per CU with the registers capped at 128 was measured and is slower, 0.290 vs 0.277 ms: the kernel is issue-bound, a
-// fourth workgroup adds spills, not throughput.)
+// the record's depth rides along).  LDS per workgroup: slots + 10 KB of tables = 40.7 KB, and 128 registers per lane: FOUR
+// workgroups per CU, one wavefront of each per SIMD.
+// (History: with the MFMA replay of round 3 four per CU -- registers capped at 128 -- spilled and was slower, 0.290 vs 0.277
+// ms, so rounds 3-4 ran three per CU with 53 KB of slots.  The stage-major replay of round 4 fits 128 registers without a
+// spill; measured then, same box: 0.1962 vs 0.2094 ms at the headline for four vs three per CU, dense workloads equal.  The
+// kernel issues VALU instructions in 39 % of its cycles -- the fourth wavefront per SIMD fills some of the rest.  Five per CU
+// would need 96 registers: 35 spilled.)
 #ifndef SR_BWD_CAP
-#define SR_BWD_CAP 1072
+#define SR_BWD_CAP 752
 #endif
 #ifndef SR_BWD_CAP_DEPTH
-#define SR_BWD_CAP_DEPTH 880
+#define SR_BWD_CAP_DEPTH 624
 #endif
-// slots a pass may assign (40-byte / 48-byte slots: 53.5 / 53 KB of LDS per workgroup with the tables); a quad's run can
+// slots a pass may assign (40-byte / 48-byte slots: 40.7 KB of LDS per workgroup with the tables); a quad's run can
 // need 256, and reads run up to 15 slots past a run
 template <bool HAS_D> struct SlotCap { static constexpr int kCap = HAS_D ? SR_BWD_CAP_DEPTH : SR_BWD_CAP; };
 constexpr int kCapSlack = 16;
 static_assert(SR_BWD_CAP >= 256 && SR_BWD_CAP_DEPTH >= 256, "one quad's entries of a chunk must always fit");
 #ifndef SR_BWD_WAVES_PER_SIMD
-#define SR_BWD_WAVES_PER_SIMD 3   // register budget: 512 / 3 = 168 per lane
+#define SR_BWD_WAVES_PER_SIMD 4   // register budget: 512 / 4 = 128 per lane
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -430,7 +434,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
 // HAS_D: the caller supplied dL/ddepth.  SplatFields' default losses leave the depth gradient empty (reference
 // arguments/__init__.py:166,168): the depth channel is then compiled out of the replay and of the LDS slots.
 template <bool HAS_D>
-__global__ void __launch_bounds__(kBlock, HAS_D ? 3 : SR_BWD_WAVES_PER_SIMD)   // with the depth channel the 48-byte slots allow three per CU anyway
+__global__ void __launch_bounds__(kBlock, SR_BWD_WAVES_PER_SIMD)
 k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Image im, const float* __restrict__ dL_dcolor,
                        const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha, float* __restrict__ slots) {
     constexpr int kF = SlotFmt<HAS_D>::kF;
