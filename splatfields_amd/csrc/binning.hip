@@ -83,33 +83,35 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) row[t] = s_hist[t];
 }
 
-// Exclusive prefix along the chunk axis, per tile column, inside one segment of kSegRows chunks.
-// grid = (tiles_padded / 64, segments); the kSegRows x 64 sub-matrix is transposed through LDS so both the
-// loads and the stores are row-contiguous.
-__global__ void __launch_bounds__(kBlock) k_colscan_local(const Geom g, const Chunking ch) {
-    __shared__ uint32_t s_m[kSegRows][65];
-    __shared__ uint32_t s_part[4][64];
-    const int col0 = blockIdx.x * 64, row0 = blockIdx.y * kSegRows;
-    for (int i = threadIdx.x; i < kSegRows * 64; i += kBlock) {
-        const int r = i >> 6, c = i & 63;
-        s_m[r][c] = (row0 + r < ch.chunks) ? g.cnt[(size_t)(row0 + r) * ch.tiles_padded + col0 + c] : 0u;
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+// Exclusive prefix along the chunk axis of the whole count matrix, per tile column, in ONE pass: a workgroup owns a strip of
+// kStripCols columns over all (<= kMaxChunks) rows and holds it in registers -- thread (row group, column) loads its
+// kStripRows consecutive rows (all loads in flight: the strip is 125 KB at 1024 chunks), prefixes them serially, the row
+// groups' totals meet in LDS, and the strip is written back once.  The column totals (a tile's list length) go to `coltot`.
+// (Rounds 2-4 scanned segments of 128 rows through LDS -- grid (tiles / 64, segments) -- and left the prefix over the
+// segments to k_scan_small and a third table to k_emit: 15 us + part of k_scan_small's 10.7 us for a 10 MB matrix.)
+#ifndef SR_STRIP_COLS
+#define SR_STRIP_COLS 32
+#endif
+constexpr int kStripCols = SR_STRIP_COLS, kStripGroups = 1024 / kStripCols, kStripRows = (kMaxChunks + kStripGroups - 1) / kStripGroups;
+__global__ void __launch_bounds__(1024) k_colscan(const Geom g, const Chunking ch) {
+    __shared__ uint32_t s_tot[kStripGroups][kStripCols + 1];
+    const int c = threadIdx.x % kStripCols, rg = threadIdx.x / kStripCols;
+    const int col = blockIdx.x * kStripCols + c, row0 = rg * kStripRows;
+    uint32_t* p = g.cnt + (size_t)row0 * ch.tiles_padded + col;
+    uint32_t x[kStripRows];
+#pragma unroll
+    for (int r = 0; r < kStripRows; ++r) x[r] = row0 + r < ch.chunks ? p[(size_t)r * ch.tiles_padded] : 0u;
     uint32_t run = 0;
-    constexpr int kPartRows = kSegRows / 4;
-    for (int r = part * kPartRows; r < (part + 1) * kPartRows; ++r) { const uint32_t x = s_m[r][c]; s_m[r][c] = run; run += x; }
-    s_part[part][c] = run;
+#pragma unroll
+    for (int r = 0; r < kStripRows; ++r) { const uint32_t t = x[r]; x[r] = run; run += t; }
+    s_tot[rg][c] = run;
     __syncthreads();
-    uint32_t base = 0;
-    for (int p2 = 0; p2 < part; ++p2) base += s_part[p2][c];
-    for (int r = part * kPartRows; r < (part + 1) * kPartRows; ++r) s_m[r][c] += base;
-    if (part == 3) g.segtot[(size_t)blockIdx.y * ch.tiles_padded + col0 + c] = base + run;
-    __syncthreads();
-    for (int i = threadIdx.x; i < kSegRows * 64; i += kBlock) {
-        const int r = i >> 6, cc = i & 63;
-        if (row0 + r < ch.chunks) g.cnt[(size_t)(row0 + r) * ch.tiles_padded + col0 + cc] = s_m[r][cc];
-    }
+    uint32_t base = 0, all = 0;
+#pragma unroll 8
+    for (int k = 0; k < kStripGroups; ++k) { const uint32_t t = s_tot[k][c]; base += k < rg ? t : 0u; all += t; }
+    if (rg == 0) g.segtot[col] = all;   // column total
+#pragma unroll
+    for (int r = 0; r < kStripRows; ++r) if (row0 + r < ch.chunks) p[(size_t)r * ch.tiles_padded] = x[r] + base;
 }
 
 void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
@@ -118,13 +120,13 @@ void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
     // images close to kMaxMatrixTiles tiles: 64 KiB of dynamic histogram + 3 KiB static exceeds the 64 KiB default limit
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_count_tiles), 0, (int)(sizeof(uint32_t) * kMaxMatrixTiles));
     hipLaunchKernelGGL(k_count_tiles, dim3(ch.chunks), dim3(kBlock), sizeof(uint32_t) * ch.tiles_padded, st, v, N, g, ch);
-    hipLaunchKernelGGL(k_colscan_local, dim3(ch.tiles_padded / 64, ch.segments), dim3(kBlock), 0, st, g, ch);
+    hipLaunchKernelGGL(k_colscan, dim3(ch.tiles_padded / kStripCols), dim3(1024), 0, st, g, ch);
 }
 
 // ---- two small prefix sums in one launch ---------------------------------------------------
 // block 0: block_sums[n_sub] -> block_offsets, grand total -> total[0]
-// block 1: per-tile totals (count-matrix path: sum of the segment totals, also producing the exclusive
-//          prefix over segments; fallback path: the atomically accumulated tile_count) -> tile_start[tiles+1];
+// block 1: per-tile totals (count-matrix path: the column totals left by k_colscan; fallback path: the atomically
+//          accumulated tile_count) -> tile_start[tiles+1];
 //          clears tile_cursor
 __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, int n_tiles, const Chunking ch, int use_matrix,
                                                       uint32_t* __restrict__ host_out) {
@@ -140,19 +142,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         if (i < n) {
             if (!tiles) v = g.block_sums[i];
             else if (!use_matrix) v = g.tile_count[i];
-            else {
-                // all segment totals of the tile are requested before the first dependent store (interleaved they were
-                // one memory round trip per segment: the stores may alias the loads as far as the compiler knows)
-                constexpr int kMaxSeg = (kMaxChunks + kSegRows - 1) / kSegRows;
-                uint32_t x[kMaxSeg];
-#pragma unroll
-                for (int sg = 0; sg < kMaxSeg; ++sg) x[sg] = sg < ch.segments ? g.segtot[(size_t)sg * ch.tiles_padded + i] : 0u;
-#pragma unroll
-                for (int sg = 0; sg < kMaxSeg; ++sg) {
-                    if (sg < ch.segments) g.segbase[(size_t)sg * ch.tiles_padded + i] = v;
-                    v += x[sg];
-                }
-            }
+            else v = g.segtot[i];   // column total of the count matrix (k_colscan)
         }
         vmax = max(vmax, v);
         const uint32_t inc = wave_inclusive_scan(v);
@@ -229,7 +219,7 @@ void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out,
 
 // ---- emit instances straight into their tile's segment -------------------------------------
 // MATRIX: the workgroup owns the same chunk as in k_count_tiles; its write cursors
-//   tile_start[t] + (prefix over earlier segments) + (prefix over earlier chunks of this segment)
+//   tile_start[t] + (prefix over earlier chunks: the count matrix after k_colscan)
 // live in LDS, so slot allocation is an LDS atomic.  The order inside a (chunk, tile) group is
 // arbitrary; the per-tile sort below imposes a total order, so the final lists are deterministic.
 template <bool MATRIX>
@@ -259,9 +249,8 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         slice = (uint32_t)(chunk % ch.slices); slices = (uint32_t)ch.slices;
         sb0 = (chunk / ch.slices) * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
         const uint32_t* row = g.cnt + (size_t)chunk * ch.tiles_padded;
-        const uint32_t* sbase = g.segbase + (size_t)(chunk / kSegRows) * ch.tiles_padded;
         const int n_tiles = v.gx * v.gy;
-        for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + sbase[t] + row[t];
+        for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + row[t];
     }
     // The chunk's sub-batches are walked one after the other (each needs the workgroup's scan and its LDS tables), but their
     // per-splat inputs are requested kAhead sub-batches at a time: a workgroup is a serial chain of sub-batches with a memory

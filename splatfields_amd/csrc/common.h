@@ -59,8 +59,8 @@ struct Geom {
                              //     last pixel (max over the quad's pixels of n_contrib); the backward replays [0, max over quads)
     // atomic-free bucketing (images up to kMaxMatrixTiles tiles): per-chunk x per-tile instance counts
     uint32_t* cnt;           // [chunks][tiles_padded] counts, then exclusive prefix over the chunks of a segment
-    uint32_t* segtot;        // [segments][tiles_padded] column totals per segment of kSegRows chunks
-    uint32_t* segbase;       // [segments][tiles_padded] exclusive prefix of segtot over segments
+    uint32_t* segtot;        // [tiles_padded] column totals of the count matrix (k_colscan); the carve keeps the [segments][tiles_padded]
+    uint32_t* segbase;       // extent of rounds 2-4 for both tables (workspace sizes are part of the callers' contract); segbase is unused
 };
 
 #ifndef SR_MAX_CHUNKS
