@@ -46,6 +46,25 @@ def hip_tile_lists(sp, st, dev):
 @pytest.mark.parametrize("n,w,h,scale", [(20000, 320, 240, None), (3000, 200, 152, 0.06), (60000, 400, 304, None)])
 def test_tile_lists_match_the_oracle(hip_device, n, w, h, scale):
     sp, cam, st, grads = make_scene(n, w, h, mean_scale=scale, view=4)
+    check_tile_lists(sp, st, n, w, h, hip_device)
+
+
+def test_a_few_lists_between_2048_and_4096_entries(hip_device):
+    """A sparse view with ONE list in the 2049..4096 class (the headline has such a tile in about half of its views): the long
+    classes walk only the head of the launch order (Geom::total[4..6], csrc/binning.hip k_scan_small) -- a tight cluster of
+    2600 small splats in front of the camera's target puts that many entries into the centre tile."""
+    n, w, h = 12000, 336, 272   # the image centre (the camera's target) is the centre of a tile
+    sp, cam, st, grads = make_scene(n, w, h, view=4)
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randperm(n, generator=g)[:2600]
+    sp["means3D"][idx] = 0.004 * torch.randn(2600, 3, generator=g)
+    sp["scales"][idx] = sp["scales"][idx].clamp(max=0.01)
+    lengths = check_tile_lists(sp, st, n, w, h, hip_device)
+    long = (lengths > 2048) & (lengths <= 4096)
+    assert 1 <= int(long.sum()) <= 8 and int(lengths.max()) <= 4096, lengths.max()
+
+
+def check_tile_lists(sp, st, n, w, h, hip_device):
     tile_start, sorted_id, total, reported, radii = hip_tile_lists(sp, st, hip_device)
     # instances = tiles of every splat's rectangle (what the facade reports and sizes the per-instance buffers by); the lists hold
     # the instances whose tile the splat can reach
@@ -95,3 +114,4 @@ def test_tile_lists_match_the_oracle(hip_device, n, w, h, scale):
             assert (hip[1:][tie] > hip[:-1][tie]).all() or not stable[hip].all(), f"tile {t}: equal depths not in splat order"
     # the exact-support culling does leave entries out, and all of them were checked
     assert checked_missing > 0
+    return tile_start[1:] - tile_start[:-1]
