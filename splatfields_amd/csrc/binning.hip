@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     __shared__ ushort4 s_rect[kBlock];
     __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat, prepared for the tile_reached test
     __shared__ uint32_t s_scan[8];
-    for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) s_hist[t] = 0u;
+    for (int t = 4 * threadIdx.x; t < ch.tiles_padded; t += 4 * kBlock) *reinterpret_cast<uint4*>(&s_hist[t]) = make_uint4(0u, 0u, 0u, 0u);   // tiles_padded % 64 == 0
     const int base_chunk = (int)blockIdx.x / ch.slices, slice = (int)blockIdx.x % ch.slices;
     const int sb0 = base_chunk * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
     // (Requesting the inputs of four sub-batches at a time, as k_emit does, was measured here in round 4: the scan stage went
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     }
     __syncthreads();
     uint32_t* row = g.cnt + (size_t)blockIdx.x * ch.tiles_padded;
-    for (int t = threadIdx.x; t < ch.tiles_padded; t += kBlock) row[t] = s_hist[t];
+    for (int t = 4 * threadIdx.x; t < ch.tiles_padded; t += 4 * kBlock) *reinterpret_cast<uint4*>(&row[t]) = *reinterpret_cast<const uint4*>(&s_hist[t]);
 }
 
 // Exclusive prefix along the chunk axis of the whole count matrix, per tile column, in ONE pass: a workgroup owns a strip of
@@ -135,29 +135,43 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
     uint32_t* dst = tiles ? g.tile_start : g.block_offsets;
     const int n = tiles ? n_tiles : n_sub;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // kPer consecutive elements per thread and round: 2500 tiles / 3907 sub-batches are ONE round (a round is a wavefront scan,
+    // a barrier, 16 LDS reads and a barrier: the kernel is two workgroups' latency chain, 10.7 us with one element per thread)
+    constexpr int kPer = 4;
     uint32_t carry = 0, vmax = 0;
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        uint32_t v = 0;
-        if (i < n) {
-            if (!tiles) v = g.block_sums[i];
-            else if (!use_matrix) v = g.tile_count[i];
-            else v = g.segtot[i];   // column total of the count matrix (k_colscan)
+    uint32_t v[kPer];   // the last round's elements: the lengths themselves when n <= 1024 * kPer
+    for (int base = 0; base < n; base += 1024 * kPer) {
+        const int i0 = base + tid * kPer;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = i0 + k;
+            v[k] = 0;
+            if (i < n) {
+                if (!tiles) v[k] = g.block_sums[i];
+                else if (!use_matrix) v[k] = g.tile_count[i];
+                else v[k] = g.segtot[i];   // column total of the count matrix (k_colscan)
+            }
+            vmax = max(vmax, v[k]);
+            sum += v[k];
         }
-        vmax = max(vmax, v);
-        const uint32_t inc = wave_inclusive_scan(v);
+        const uint32_t inc = wave_inclusive_scan(sum);
         if (lane == 63) s_wave[w] = inc;
         __syncthreads();
         uint32_t wave_base = 0, all = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { const uint32_t t = s_wave[k]; if (k < w) wave_base += t; all += t; }
-        if (i < n) {
-            dst[i] = carry + wave_base + inc - v;
-            if (tiles) g.tile_cursor[i] = 0u;
+        uint32_t run = carry + wave_base + inc - sum;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = i0 + k;
+            if (i < n) { dst[i] = run; if (tiles) g.tile_cursor[i] = 0u; }
+            run += v[k];
         }
         carry += all;
         __syncthreads();
     }
+    const bool in_regs = n <= 1024 * kPer;   // uniform
     // host_out: two words of pinned host memory (sr_forward's instance count / longest list read-back): stored from here,
     // the host reads them after the event that follows this kernel -- no copy command in the stream
     if (tid == 0) { if (tiles) dst[n] = carry; else { g.total[0] = carry; if (host_out) host_out[0] = carry; } }
@@ -177,9 +191,15 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         const float to_class = 255.0f / (float)longest;   // class = 255 - floor(255 len / longest), in float: no 64-bit division
         if (tid < 256) s_hist[tid] = 0u;
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const uint32_t len = dst[i + 1] - dst[i];   // written by this workgroup above (barriers in between)
-            atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u);
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                if (tid * kPer + k < n) atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)v[k] * to_class))], 1u);
+        } else {
+            for (int i = tid; i < n; i += 1024) {
+                const uint32_t len = dst[i + 1] - dst[i];   // written by this workgroup above (barriers in between)
+                atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u);
+            }
         }
         __syncthreads();
         if (w == 0) {  // exclusive prefix over the 256 classes: 4 per lane
@@ -204,9 +224,16 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
             g.total[4 + tid] = cand;
         }
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) {
-            const uint32_t len = dst[i + 1] - dst[i];
-            g.tile_order[atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u)] = (uint32_t)i;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                if (tid * kPer + k < n)
+                    g.tile_order[atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)v[k] * to_class))], 1u)] = (uint32_t)(tid * kPer + k);
+        } else {
+            for (int i = tid; i < n; i += 1024) {
+                const uint32_t len = dst[i + 1] - dst[i];
+                g.tile_order[atomicAdd(&s_hist[255u - min(255u, (uint32_t)((float)len * to_class))], 1u)] = (uint32_t)i;
+            }
         }
     }
 }
@@ -250,7 +277,12 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         sb0 = (chunk / ch.slices) * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
         const uint32_t* row = g.cnt + (size_t)chunk * ch.tiles_padded;
         const int n_tiles = v.gx * v.gy;
-        for (int t = threadIdx.x; t < n_tiles; t += kBlock) s_cur[t] = g.tile_start[t] + row[t];
+        // four tiles per thread and step (rows and tables are 256-byte aligned; the last step may read up to 3 words behind
+        // tile_start[n_tiles], inside the table's alignment padding, for cursors nobody uses)
+        for (int t = 4 * threadIdx.x; t < n_tiles; t += 4 * kBlock) {
+            const uint4 a = *reinterpret_cast<const uint4*>(&g.tile_start[t]), r = *reinterpret_cast<const uint4*>(&row[t]);
+            *reinterpret_cast<uint4*>(&s_cur[t]) = make_uint4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+        }
     }
     // The chunk's sub-batches are walked one after the other (each needs the workgroup's scan and its LDS tables), but their
     // per-splat inputs are requested kAhead sub-batches at a time: a workgroup is a serial chain of sub-batches with a memory
