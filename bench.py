@@ -221,7 +221,8 @@ def blend_work_counters(n, width, height, mean_scale):
             "lane_efficiency": d["lane_efficiency"], "bucket_fill": d["bucket_fill"], "list_chunks": d["chunks"],
             "wave_cycle_share_by_phase": share,
             "note": "pair = (pixel, list entry) on which alpha is evaluated; blended = alpha >= 1/255 and not behind the pixel's "
-                    "last contributor; counted on one fwd+bwd of view 1 by the -DSR_BWD_STATS build (tools/bwd_stats.py)"}
+                    "last contributor; counted on one fwd+bwd of view 1 by the -DSR_BWD_STATS build (tools/bwd_stats.py), which runs three workgroups per CU "
+                    "(its counters cost registers) where the product runs four: the phase shares are its own"}
 
 
 def median(xs):

@@ -89,7 +89,9 @@ def build_stats_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and STATS_LIB_PATH.exists() and not any(
             (CSRC / f).stat().st_mtime > STATS_LIB_PATH.stat().st_mtime for f in SOURCES + HEADERS):
         return STATS_LIB_PATH
-    return build_library(force=True, verbose=verbose, out=STATS_LIB_PATH, defines=["SR_BWD_STATS"])
+    # the counters cost registers: with the product's cap of 128 (four workgroups per CU) the counting build spills 22 vector +
+    # 41 scalar registers and its phase shares measure the spills; three wavefronts per SIMD (168 registers) hold them
+    return build_library(force=True, verbose=verbose, out=STATS_LIB_PATH, defines=["SR_BWD_STATS", "SR_BWD_WAVES_PER_SIMD=3"])
 
 
 if __name__ == "__main__":
