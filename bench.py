@@ -308,7 +308,8 @@ def deform_network_probe():
             "product_decoderfree_full_step_ms", "product_decoderfree_net_forward_ms", "product_graphed_net_fwd_bwd_ms",
             "product_graphed_full_step_ms", "product_decoderfree_graphed_net_fwd_bwd_ms", "product_decoderfree_graphed_full_step_ms",
             "product_graphed_error", "product_decoderfree_graphed_error", "product_launches_per_step",
-            "product_decoderfree_launches_per_step", "product_mfma_frac", "product_decoderfree_mfma_frac", "mlp_macs_per_splat"]
+            "product_decoderfree_launches_per_step", "product_library_launches_per_step",
+            "product_decoderfree_library_launches_per_step", "product_mfma_frac", "product_decoderfree_mfma_frac", "mlp_macs_per_splat"]
     res = {k: d[k] for k in keep if k in d}
     res["name"] = ("4-D config: deform network (stand-in of the reference's shapes), PyTorch-ROCm vs fused MLP kernels; product_* = "
                    "splatfields_amd.deform_field.SplatFields (tri-plane lookup, ResField composition and MLPs on HIP kernels) with the same "

@@ -306,10 +306,15 @@ def main():
         try:
             from torch.profiler import ProfilerActivity, profile
             torch.cuda.synchronize()
-            with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                p_full_step()
+            # (with the device activity alone the trace loses records from run to run -- 307 / 67 / 26 for the same step; with
+            # the host activity enabled as well the count is stable and agrees with rocprofv3's kernel trace)
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for _ in range(3):
+                    p_full_step()
                 torch.cuda.synchronize()
-            res[key + "_launches_per_step"] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+            dev_events = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+            res[key + "_launches_per_step"] = len(dev_events) / 3.0   # kernels + memsets / copies on the device
+            res[key + "_library_launches_per_step"] = sum(1 for e in dev_events if e.name.startswith(("sr::", "void sr::"))) / 3.0
         except Exception as e:  # noqa: BLE001 -- a profiler that is not available must not cost the timings
             res[key + "_launches_per_step"] = None
             res[key + "_launches_error"] = repr(e)[:200]
