@@ -172,7 +172,8 @@ int validate(const SrView* view, const SrSplats* s) {
         if (s->raw_params & ~(SR_RAW_SCALES | SR_RAW_OPACITY | SR_RAW_ROTATIONS | SR_FORWARD_ONLY)) return fail("unknown bits in raw_params");
         if (s->cov3D_precomp && (s->raw_params & (SR_RAW_SCALES | SR_RAW_ROTATIONS))) return fail("raw scales/rotations with cov3D_precomp");
     }
-    if ((sr::tiles_x(view->image_width) > 65535) || (sr::tiles_y(view->image_height) > 65535)) return fail("image too large");
+    // tile coordinates are stored in 12 bits (Geom::rect carries the small rectangles' reach mask in the top nibbles, common.h)
+    if ((sr::tiles_x(view->image_width) > sr::kMaxTilesPerSide) || (sr::tiles_y(view->image_height) > sr::kMaxTilesPerSide)) return fail("image too large (more than 65520 pixels a side)");
     return 0;
 }
 

@@ -56,26 +56,31 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
         uint32_t touched = 0;
         ushort4 rect = make_ushort4(0, 0, 0, 0);
         float4 r0 = make_float4(0.f, 0.f, -1.f, 0.f), r1 = r0;
-        if (idx < N) { touched = g.touched[idx]; rect = g.rect[idx]; if (touched >= kCullMinTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; } }
-        float4 e0, e1;
-        tile_test_prepare(r0, r1, e0, e1);
+        if (idx < N) {
+            touched = g.touched[idx]; rect = g.rect[idx];
+            if (touched > kMaskTiles) { r0 = g.rec[4 * (size_t)idx]; r1 = g.rec[4 * (size_t)idx + 1]; }   // larger rectangles are tested here
+        }
+        const uint32_t mask = rect_mask16(rect);   // bit k of a small rectangle's mask (bit 15: mask present)
+        const ushort4 packed = rect;
+        rect = rect_clean(rect);
         const bool direct = ch.slices == 1 && touched <= kDirectTiles;
         if (direct && touched > 0u) {
+            uint32_t k = 0;
             for (uint32_t ty = rect.y; ty < rect.w; ++ty)
-                for (uint32_t tx = rect.x; tx < rect.z; ++tx)
-                    if (touched < kCullMinTiles || tile_reached(e0, e1, tx, ty)) atomicAdd(&s_hist[ty * (uint32_t)v.gx + tx], 1u);  // LDS atomic
+                for (uint32_t tx = rect.x; tx < rect.z; ++tx, ++k)
+                    if ((mask >> k) & 1u) atomicAdd(&s_hist[ty * (uint32_t)v.gx + tx], 1u);  // LDS atomic
         }
         const uint32_t coop = direct ? 0u : touched;
         if (!__syncthreads_or(coop != 0u)) continue;   // uniform: no large rectangle in this sub-batch (also protects s_off reuse)
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(coop, s_scan, total);
         s_off[threadIdx.x] = excl;
-        s_rect[threadIdx.x] = rect;
-        s_r0[threadIdx.x] = e0; s_r1[threadIdx.x] = e1;
+        s_rect[threadIdx.x] = packed;
+        tile_test_prepare(r0, r1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
-            if (rect_tiles < kCullMinTiles || tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&s_hist[tile], 1u);  // LDS atomic
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t k, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t w) {
+            if ((w & kRectMasked) ? (w >> k) & 1u : tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&s_hist[tile], 1u);  // LDS atomic
         }, (uint32_t)slice, (uint32_t)ch.slices);
     }
     __syncthreads();
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
     // round trip per link otherwise (0.0317 -> 0.0298 ms at the headline)
     constexpr int kAhead = 4;
     for (int sbg = sb0; sbg < sb1; sbg += kAhead) {
-        uint32_t touched_a[kAhead], dbits_a[kAhead], base_a[kAhead];
+        uint32_t touched_a[kAhead], word_a[kAhead], dbits_a[kAhead], base_a[kAhead];
         ushort4 rect_a[kAhead];
         float4 r0_a[kAhead], r1_a[kAhead];
 #pragma unroll
@@ -309,32 +314,34 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         for (int u = 0; u < kAhead; ++u) {
             const int idx = (sbg + u) * kBlock + threadIdx.x;
             r0_a[u] = make_float4(0.f, 0.f, -1.f, 0.f); r1_a[u] = r0_a[u];
-            if (touched_a[u] >= kCullMinTiles) { r0_a[u] = g.rec[4 * (size_t)idx]; r1_a[u] = g.rec[4 * (size_t)idx + 1]; }
+            if (touched_a[u] > kMaskTiles) { r0_a[u] = g.rec[4 * (size_t)idx]; r1_a[u] = g.rec[4 * (size_t)idx + 1]; }   // as in the count pass
+            word_a[u] = rect_mask16(rect_a[u]);   // bit k of a small rectangle's mask (bit 15: mask present); rect_a stays packed
         }
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const int sb = sbg + u;
             if (sb >= sb1) break;   // uniform
             const int idx = sb * kBlock + threadIdx.x;
+            const uint32_t touched = touched_a[u], mask = word_a[u];
             // two prefixes over the sub-batch: all instances (their indices; `offsets`) and those of the rectangles that take the
             // cooperative expansion -- the ones above kDirectTiles tiles (k_count_tiles makes the same split)
-            const bool direct = slices == 1u && touched_a[u] <= kDirectTiles;
-            const uint32_t coop = direct ? 0u : touched_a[u];
+            const bool direct = slices == 1u && touched <= kDirectTiles;
+            const uint32_t coop = direct ? 0u : touched;
             uint32_t total, coop_total;
             uint32_t coop_excl;
-            const uint32_t excl = block_exclusive_scan2(touched_a[u], coop, s_scan, total, coop_excl, coop_total);  // leading barrier protects LDS reuse
+            const uint32_t excl = block_exclusive_scan2(touched, coop, s_scan, total, coop_excl, coop_total);  // leading barrier protects LDS reuse
             const uint32_t base = base_a[u];
             if (idx < N) g.offsets[idx] = base + excl;
             if (slice == 0u)
                 for (uint32_t i = threadIdx.x; i < total; i += kBlock) b.reached[base + i] = 0;   // consecutive threads, consecutive bytes
             const uint32_t first_splat = (uint32_t)sb * kBlock;
-            float4 e0, e1;
-            tile_test_prepare(r0_a[u], r1_a[u], e0, e1);
-            if (direct && touched_a[u] > 0u) {
+            if (direct && touched > 0u) {
                 const uint64_t entry = ((uint64_t)dbits_a[u] << 32) | (uint64_t)(first_splat + threadIdx.x);
-                for (uint32_t ty = rect_a[u].y; ty < rect_a[u].w; ++ty)
-                    for (uint32_t tx = rect_a[u].x; tx < rect_a[u].z; ++tx) {
-                        if (touched_a[u] >= kCullMinTiles && !tile_reached(e0, e1, tx, ty)) continue;   // as in the count pass
+                uint32_t k = 0;
+                const ushort4 rc = rect_clean(rect_a[u]);
+                for (uint32_t ty = rc.y; ty < rc.w; ++ty)
+                    for (uint32_t tx = rc.x; tx < rc.z; ++tx, ++k) {
+                        if (!((mask >> k) & 1u)) continue;   // as in the count pass
                         const uint32_t tile = ty * (uint32_t)v.gx + tx;
                         uint32_t slot;
                         if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
@@ -346,11 +353,11 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
             s_off[threadIdx.x] = coop_excl;
             s_rect[threadIdx.x] = rect_a[u];
             s_depth[threadIdx.x] = dbits_a[u];
-            s_r0[threadIdx.x] = e0; s_r1[threadIdx.x] = e1;
+            tile_test_prepare(r0_a[u], r1_a[u], s_r0[threadIdx.x], s_r1[threadIdx.x]);
             if (threadIdx.x == 0) s_off[kBlock] = coop_total;
             __syncthreads();
-            for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
-                if (rect_tiles >= kCullMinTiles && !tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) return;   // as in the count pass
+            for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t k, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t w) {   // w: as in the count pass
+                if (!((w & kRectMasked) ? (w >> k) & 1u : tile_reached(s_r0[e], s_r1[e], tile_x, tile_y))) return;
                 uint32_t slot;
                 if constexpr (MATRIX) slot = atomicAdd(&s_cur[tile], 1u);  // LDS
                 else slot = g.tile_start[tile] + atomicAdd(&g.tile_cursor[tile], 1u);

@@ -409,6 +409,30 @@ constexpr uint32_t kCullMinTiles = SR_CULL_MIN_TILES;
 #endif
 constexpr uint32_t kDirectTiles = SR_DIRECT_TILES;   // rectangles up to this many tiles are walked by their own thread in the two instance passes
                                                     // (round 4, headline scan + emit: 4 -> +1.3 us, 6 -> -3.3, 9 -> -4.4, 16 -> -4.4; dense 100 k x 0.05: +1)
+// Rectangles of up to kMaskTiles tiles get the outcome of the test once, in k_preprocess: bit k of the mask = tile k of the
+// rectangle (row-major) can be reached (all ones below kCullMinTiles).  The two instance passes read the bit instead of the
+// ellipse -- one evaluation instead of three, no 32-byte record read per splat in either pass, and the count pass and the
+// scatter cannot disagree.  The 16 bits (bit 15 = mask present, bits 0..14 = mask) ride in the top nibbles of the four
+// 16-bit fields of Geom::rect (tile coordinates are < 4096: images up to 65520 pixels a side, checked by the C ABI).
+// (Packed into Geom::touched they cost k_preprocess_backward 2.4 us: its loads queued behind the decode of that word.)
+#ifndef SR_MASK_TILES
+#define SR_MASK_TILES 9
+#endif
+constexpr uint32_t kMaskTiles = SR_MASK_TILES;   // <= 15 (the mask has 15 bits).  Measured 9 vs 15: headline equal; 100 k x 0.05: k_preprocess +1.9 vs +4.5 us
+                                                 // (a wavefront pays the longest mask loop of its 64 splats)
+constexpr uint32_t kRectMasked = 0x8000u;
+constexpr int kMaxTilesPerSide = 4095;
+static_assert(kDirectTiles <= kMaskTiles, "the per-thread walk reads the mask");
+__host__ __device__ inline ushort4 rect_pack(ushort4 r, uint32_t m16) {
+    return make_ushort4((unsigned short)(r.x | ((m16 & 0xfu) << 12)), (unsigned short)(r.y | (((m16 >> 4) & 0xfu) << 12)),
+                        (unsigned short)(r.z | (((m16 >> 8) & 0xfu) << 12)), (unsigned short)(r.w | (((m16 >> 12) & 0xfu) << 12)));
+}
+__host__ __device__ inline uint32_t rect_mask16(ushort4 p) {
+    return (uint32_t)(p.x >> 12) | ((uint32_t)(p.y >> 12) << 4) | ((uint32_t)(p.z >> 12) << 8) | ((uint32_t)(p.w >> 12) << 12);
+}
+__host__ __device__ inline ushort4 rect_clean(ushort4 p) {
+    return make_ushort4((unsigned short)(p.x & 0xfffu), (unsigned short)(p.y & 0xfffu), (unsigned short)(p.z & 0xfffu), (unsigned short)(p.w & 0xfffu));
+}
 // The per-splat half of the test is done once (tile_test_prepare, by the thread that stages the splat of a sub-batch): e0 =
 // (centre x, centre y, threshold, A), e1 = (2 B, C, 1 / A, 1 / C) of the quadratic form; tile_reached then costs the four
 // edge minima only.  A splat that can never be seen has threshold < 0.

@@ -11,7 +11,8 @@ namespace sr {
 #ifdef __HIPCC__
 // s_off: [kBlock+1] exclusive offsets, s_off[kBlock] = block total.  s_rect: [kBlock] tile rects.
 // slice / slices: only the slice-th of `slices` equal parts of the instance list is walked.
-// f(local_splat, k_within_splat, tile_index, local_instance, tile_x, tile_y, tiles in the splat's rect)
+// s_rect holds the rectangles as Geom::rect stores them (top nibbles = reach mask of a small rectangle, common.h).
+// f(local_splat, k_within_splat, tile_index, local_instance, tile_x, tile_y, the rectangle's 16 mask bits)
 template <typename F>
 __device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, const ushort4* s_rect, int gx, F&& f, uint32_t slice = 0, uint32_t slices = 1) {
     const uint32_t all = s_off[kBlock];
@@ -40,14 +41,15 @@ __device__ __forceinline__ void for_each_block_instance(const uint32_t* s_off, c
             const uint32_t i = i0 + (uint32_t)u * kBlock;
             if (i >= total) break;
             const uint32_t k = i - s_off[lo[u]];
-            const ushort4 r = s_rect[lo[u]];
+            const ushort4 packed = s_rect[lo[u]];
+            const ushort4 r = rect_clean(packed);
             const uint32_t w = (uint32_t)(r.z - r.x);
             // k / w without the 25-instruction integer division: k < 2^22 (a rectangle has at most gx * gy tiles), so the
             // float quotient of k + 0.5 is off by less than the 0.5 / w that separates it from the next integer; corrected anyway
             uint32_t ty = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
             if (ty * w > k) --ty; else if ((ty + 1u) * w <= k) ++ty;
             const uint32_t tx = k - ty * w;
-            f(lo[u], k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, w * (uint32_t)(r.w - r.y));
+            f(lo[u], k, (uint32_t)(r.y + ty) * (uint32_t)gx + (uint32_t)r.x + tx, i, (uint32_t)r.x + tx, (uint32_t)r.y + ty, rect_mask16(packed));
         }
     }
 }

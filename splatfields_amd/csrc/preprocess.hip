@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
-    uint32_t touched = 0, depth_bits = 0;
+    uint32_t touched = 0, depth_bits = 0, mask16 = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
     float4 ell0 = make_float4(0.f, 0.f, -1.f, 0.f), ell1 = ell0, rec2 = ell0;
     uint32_t rect_bits = 0;
@@ -289,7 +289,21 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
             }
         }
         radii[idx] = out_radius;
-        g.rect[idx] = rect;
+        // small rectangles: which of their tiles the ellipse reaches, decided here once (common.h, kMaskTiles)
+        if (touched > 0u && touched <= kMaskTiles) {
+            uint32_t mask = (1u << touched) - 1u;
+            if (touched >= kCullMinTiles) {
+                float4 e0, e1;
+                tile_test_prepare(ell0, ell1, e0, e1);
+                mask = 0u;
+                uint32_t k = 0;
+                for (uint32_t ty = rect.y; ty < rect.w; ++ty)
+                    for (uint32_t tx = rect.x; tx < rect.z; ++tx, ++k)
+                        if (tile_reached(e0, e1, tx, ty)) mask |= 1u << k;
+            }
+            mask16 = kRectMasked | mask;
+        }
+        g.rect[idx] = rect_pack(rect, mask16);
         g.touched[idx] = touched;
         g.depth_bits[idx] = depth_bits;
         g.flags[idx] = flags;
@@ -315,12 +329,13 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         // fallback for very large images: per-tile counts with global atomics
         // (block-cooperative expansion keeps large splats from serialising a lane)
         s_off[threadIdx.x] = excl;
-        s_rect[threadIdx.x] = rect;
+        s_rect[threadIdx.x] = rect_pack(rect, mask16);
         tile_test_prepare(ell0, ell1, s_r0[threadIdx.x], s_r1[threadIdx.x]);
         if (threadIdx.x == 0) s_off[kBlock] = total;
         __syncthreads();
-        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t rect_tiles) {
-            if (rect_tiles < kCullMinTiles || tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&g.tile_count[tile], 1u);
+        for_each_block_instance(s_off, s_rect, v.gx, [&](int e, uint32_t k, uint32_t tile, uint32_t, uint32_t tile_x, uint32_t tile_y, uint32_t w) {
+            // the same decision as k_emit<false>: the mask where there is one
+            if ((w & kRectMasked) ? (w >> k) & 1u : tile_reached(s_r0[e], s_r1[e], tile_x, tile_y)) atomicAdd(&g.tile_count[tile], 1u);
         });
     }
 }
