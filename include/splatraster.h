@@ -52,8 +52,8 @@ extern "C" {
 #define SR_TILE 16 /* binning tile edge in pixels (upstream BLOCK_X = BLOCK_Y) */
 
 typedef struct SrView {
-    int image_height;
-    int image_width;
+    int image_height;         /* 1..65520: at most 4095 tiles a side (tile coordinates are stored in 12 bits) */
+    int image_width;          /* 1..65520 */
     float tanfovx;
     float tanfovy;
     float scale_modifier;

@@ -57,6 +57,12 @@ def test_argument_validation_errors_without_gpu(lib):
     inst = C.c_longlong(0)
     rc = lib.sr_forward_prepare(C.byref(view), C.byref(splats), None, None, C.byref(inst), None)
     assert rc != 0 and b"device pointers" in lib.sr_last_error()
+    # tile coordinates are stored in 12 bits (the top nibbles of Geom::rect carry the reach mask): 65520 pixels a side at most
+    fake = C.c_void_p(4096)   # never dereferenced: the size check comes first
+    for h, w, ok_size in ((64, 65536, False), (65537, 64, False), (65520, 65520, True)):
+        view = _lib.SrView(h, w, 0.5, 0.5, 1.0, 0, 0, 0, 0, fake, fake, fake, fake)
+        rc = lib.sr_forward_prepare(C.byref(view), C.byref(splats), None, None, C.byref(inst), None)
+        assert rc != 0 and (b"image too large" in lib.sr_last_error()) == (not ok_size), (h, w, lib.sr_last_error())
 
 
 def test_facade_validation_and_no_cpu_fallback():

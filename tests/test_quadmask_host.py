@@ -15,3 +15,13 @@ def test_quad_mask_is_a_tight_superset_of_the_blended_pixels(tmp_path):
     assert cases == 200000 and missed == 0
     assert nonempty > 0.5 * cases                      # the random splats do reach the tile
     assert mask_quads <= 1.05 * true_quads             # conservative, but by no more than 5 % of the quads
+
+
+def test_reach_mask_packing_of_the_tile_rectangles(tmp_path):
+    """Geom::rect carries the small rectangles' reach mask in the top nibbles of its four 12-bit tile coordinates
+    (csrc/common.h): host build of the three helpers, round trip over a million random cases."""
+    exe = tmp_path / "rectmask_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-value", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "native", "rectmask_check.hip")], check=True, capture_output=True)
+    cases, bad = map(int, subprocess.run([str(exe), "1000000"], check=True, capture_output=True, text=True).stdout.split())
+    assert cases == 1000000 and bad == 0
