@@ -420,6 +420,12 @@ constexpr uint32_t kDirectTiles = SR_DIRECT_TILES;   // rectangles up to this ma
 #endif
 constexpr uint32_t kMaskTiles = SR_MASK_TILES;   // <= 15 (the mask has 15 bits).  Measured 9 vs 15: headline equal; 100 k x 0.05: k_preprocess +1.9 vs +4.5 us
                                                  // (a wavefront pays the longest mask loop of its 64 splats)
+#ifndef SR_MASK_MIN_TILES
+#define SR_MASK_MIN_TILES 1
+#endif
+constexpr uint32_t kMaskMinTiles = SR_MASK_MIN_TILES;   // masked rectangles of at least this many tiles are tested tile by tile: every one.
+                                                       // (With the test paid once, the one- to three-tile rectangles are worth it too -- 4 / 2 / 1: k_preprocess
+                                                       // +0 / +1.7 / +1.7 us, scatter + sort + blend pair -0 / -2.3 / -4.3 us at the headline.)
 constexpr uint32_t kRectMasked = 0x8000u;
 constexpr int kMaxTilesPerSide = 4095;
 static_assert(kDirectTiles <= kMaskTiles, "the per-thread walk reads the mask");

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
         // small rectangles: which of their tiles the ellipse reaches, decided here once (common.h, kMaskTiles)
         if (touched > 0u && touched <= kMaskTiles) {
             uint32_t mask = (1u << touched) - 1u;
-            if (touched >= kCullMinTiles) {
+            if (touched >= kMaskMinTiles) {
                 float4 e0, e1;
                 tile_test_prepare(ell0, ell1, e0, e1);
                 mask = 0u;
