@@ -443,13 +443,19 @@ def main():
         state["mode"] = modes[modes.index(state["mode"]) + 1]
     t_start = time.perf_counter()
     from splatfields_amd.view_parallel import ExchangeStats
+    # Before the W warmup steps every view of the cycle is rendered once (untimed, like the library build): the buffer sizes of
+    # the facade follow the largest instance count seen, and with W smaller than the number of views the first timed steps
+    # would otherwise be the ones that meet a new view -- and pay the allocator's hipMallocs (round 3's driver line, W = 5:
+    # one 80 ms step in 20).  A training run is in this state after its first epoch.
+    for i in range(len(cams)):
+        one_step(i)
     for i in range(args.warmup):
         one_step(i)
     fence()
     # Timed region (task contract): exactly K steps between barrier + synchronize on both sides, max over ranks -> `value`.
-    # Inside it every step is also bracketed by HIP events on the launch stream; `ms_per_step` is the MEDIAN of those
-    # per-step times (robust against the odd slow step; box-to-box variance is +-3 %), the wall-clock mean is
-    # reported beside it.  Recording an event costs the stream nothing measurable.
+    # Inside it every step is also bracketed by HIP events on the launch stream: `ms_per_step_median` is the median of those
+    # per-step times (robust against the odd slow step), `ms_per_step` the wall-clock mean `value` is computed from.
+    # Recording an event costs the stream nothing measurable.
     ExchangeStats.reset(world > 1 or args.force_dp_path)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     stream = torch.cuda.current_stream(dev)

@@ -145,3 +145,20 @@ def test_mlp_entry_points_refuse_bad_descriptions_without_touching_a_device():
     assert lib.sr_mlp_weight_grad_workspace(1000, 1, bad) == 0
     assert lib.sr_mlp_weight_grad(1000, 1, bad, base, 1 << 30, None) != 0 and b"unsupported job list" in lib.sr_last_error()
     assert lib.sr_mlp_weight_grad(0, 2, good, base, 1 << 30, None) != 0
+
+
+def test_capacity_steps_are_coarse_and_sufficient():
+    """The facade sizes the binning buffer and the backward scratch by a capacity that follows the largest instance count seen:
+    quantised (eight steps per power of two) so that the per-view fluctuation of a training loop does not change the two
+    allocation sizes every time a new maximum appears (splatfields_amd/rasterizer.py: _round_capacity)."""
+    from splatfields_amd.rasterizer import _round_capacity
+    prev = 0
+    for inst in [0, 1, 999, 65_535, 65_536, 100_000, 2_291_306, 2_300_000, 2_350_000, 6_660_000, 25_400_000, 3_000_000_000]:
+        c = _round_capacity(inst)
+        assert c >= int(inst * 1.25) + 1024 and c >= 1 << 16          # never below what the count needs with its headroom
+        assert c <= (int(inst * 1.25) + 1024) * 1.125 + 1 or c == 1 << 16   # at most one step above it
+        assert c >= prev                                               # monotone
+        prev = c
+    # the headline's views (2.27 .. 2.31 M instances: 9 distinct counts, 9 sizes if the capacity followed them exactly) see at most
+    # one change of size
+    assert len({_round_capacity(i) for i in range(2_270_000, 2_310_001, 5_000)}) <= 2
