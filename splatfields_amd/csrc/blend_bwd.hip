@@ -480,8 +480,8 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
     // (when its (quad, entry) pairs exceed the slot buffer, the quads are served in several passes instead of shortening it).
     // A chunk's entries are loaded at the end of the previous chunk, synchronously: measured on MI355X, every form of
     // prefetch tried here -- a second register set swapped by unrolling the loop twice, LDS-direct loads into a staging area
-    // (0.337 ms: seven small copies per entry saturate the CU's copy path) -- was no faster than this (0.273 ms); with three
-    // workgroups per CU the other workgroups' replay already covers a chunk's gather.
+    // (0.337 ms: seven small copies per entry saturate the CU's copy path) -- was no faster than this (0.273 ms); the other
+    // workgroups of the CU (three then, four since round 4) already cover a chunk's gather with their replay.
     constexpr int kChunk = kBlocks * kBlkEntries;
     static_assert(kChunk == kBlock, "one list entry per thread");
     if (bmax == 0) return;   // uniform: empty list, or no pixel of the tile blended anything
