@@ -317,13 +317,63 @@ def deform_network_probe():
     return res
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher: start the N ranks here (torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1) with the same arguments and hand their output through -- a run that silently used one GPU and
+    printed n_gpus: 1 would lose the first multi-GPU measurement to a launcher assumption."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE in the environment: launching {args.gpus} ranks "
+          f"(torch.distributed.run, 127.0.0.1:{port})", file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def headline_parity(kept: dict, n, height, width, use_sh, sh_degree, mean_scale, dev) -> dict:
+    """One fwd+bwd of the HIP path on the oracle's inputs (view `kept['view']` of the seeded workload) compared with the C oracle's
+    outputs and gradients (oracle/parity.py)."""
+    import math
+    from oracle import parity as P
+    from splatfields_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+    sp = make_splats(n, seed=1234, device=dev, mean_scale=mean_scale)
+    names = ["means3D", "scales", "rotations", "opacities", "shs" if use_sh else "colors_precomp"]
+    leaf = {k: sp[k].clone().requires_grad_(True) for k in names}
+    m2 = torch.zeros_like(leaf["means3D"], requires_grad=True)
+    cam = make_camera(kept["view"], width, height, device=dev)
+    gi, gd, ga = make_upstream_grads(height, width, device=dev)
+    rs = GaussianRasterizationSettings(
+        image_height=height, image_width=width, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+    color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+        means3D=leaf["means3D"], means2D=m2, opacities=leaf["opacities"], shs=leaf["shs"] if use_sh else None,
+        colors_precomp=None if use_sh else leaf["colors_precomp"], scales=leaf["scales"], rotations=leaf["rotations"])
+    torch.autograd.backward((color, depth, alpha), (gi, gd, ga))
+    torch.cuda.synchronize()
+    out = {"color": color.detach().cpu(), "depth": depth.detach().cpu(), "alpha": alpha.detach().cpu(), "radii": radii.cpu()}
+    g = {k: v.grad.detach().cpu() for k, v in leaf.items()}
+    g["means2D"] = m2.grad.detach().cpu()
+    res = P.compare(out, g, kept["out"], kept["grads"])
+    res["against"] = "oracle/raster_ref.c (fp32, explicit backward), the run timed as cpu_baseline: same inputs, view %d, whole image" % kept["view"]
+    res["tolerance"] = "north star: <= 1e-4 max relative image error on pixels whose threshold decisions do not flip (tests/)"
+    return res
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:   # a hard error either way: the line's n_gpus must be what was asked for
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
     dev = torch.device("cuda", 0 if args.single_device else local_rank)
@@ -341,6 +391,8 @@ def main():
     from splatfields_amd.view_parallel import allreduce_gradients, sh_gather_step, sh_sharded_step
     import math
 
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {dist.get_world_size()} ranks joined the process group")
     lib = _lib.load()
     N, H, W = args.splats, args.height, args.width
     use_sh = args.color == "sh"
@@ -457,6 +509,7 @@ def main():
     # per-step times (robust against the odd slow step), `ms_per_step` the wall-clock mean `value` is computed from.
     # Recording an event costs the stream nothing measurable.
     ExchangeStats.reset(world > 1 or args.force_dp_path)
+    rz.host_sync_counters(reset=True)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     stream = torch.cuda.current_stream(dev)
     t0 = time.perf_counter()
@@ -480,6 +533,7 @@ def main():
     value = world * N * H * W * args.steps / elapsed
     exchange = ExchangeStats.summary() if ExchangeStats.enabled else None
     ExchangeStats.reset(False)
+    host_sync = rz.host_sync_counters()
 
     def progress(msg):
         if rank == 0:
@@ -527,6 +581,10 @@ def main():
                               "frac_from_median": b_alg / (ms_median * 1e-3) / HBM_PEAK,
                               "frac_vs_measured_peak_6.29TBs": b_alg / (ms_per_step * 1e-3) / 6.29e12},
         "stage_ms": stage_ms, "stage_ms_sum": sum(stage_ms.values()),
+        # host synchronisations of the forward inside the timed region (sr_debug_counters): forwards that waited for their
+        # instance count (sr_forward: first render of a camera) vs forwards launched without waiting (sr_forward_async)
+        "host_sync": dict(host_sync, async_forward=rz.async_forward_enabled(),
+                          note="timed steps only; the cameras of the cycle were rendered before, so no forward should wait"),
         # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
         "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }
@@ -597,7 +655,19 @@ def main():
         from oracle.cpu_baseline import run_cpu_baseline, run_torch_oracle_config0  # the oracle: only the timed CPU baseline
         out["cpu_baseline_torch_config0"] = run_torch_oracle_config0()
         progress("torch oracle config 0 done")
-        out["cpu_baseline"] = run_cpu_baseline(N, H, W, use_sh, args.sh_degree, args.cpu_seconds)
+        kept = {}
+        out["cpu_baseline"] = run_cpu_baseline(N, H, W, use_sh, args.sh_degree, args.cpu_seconds, keep=kept)
+        progress("C oracle baseline done")
+        # ---- parity of the measured path, on the measured workload, in the same run (north star: <= 1e-4 image error) ----
+        # the oracle's results of the baseline run above (whole image, view 0) against one forward+backward of the HIP path on
+        # the same inputs; checker only, after the timed region
+        if kept:
+            try:
+                out["parity"] = headline_parity(kept, N, H, W, use_sh, args.sh_degree, args.mean_scale, dev)
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not cost the headline line
+                out["parity"] = {"error": repr(e)[:300]}
+        else:
+            out["parity"] = {"skipped": "the bounded CPU sample did not cover the whole image (--cpu-seconds)"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -48,7 +48,11 @@
 extern "C" {
 #endif
 
-#define SR_VERSION 3
+/* Version of this ABI; sr_version() returns the library's.  A caller built against another version must not use the library
+ * (the binding checks at load).  History: 3 = rounds 2-3; 4 = round 4's additions made official (sr_backward's `binning` is
+ * written; sr_backward_blend / sr_backward_splats / sr_debug_snapshot; Geom's eight count words; images of at most 4095 tiles a
+ * side; record quarter 3 / block_offsets carry the instance index) + round 5: sr_forward_async / sr_ticket_* / sr_debug_counters. */
+#define SR_VERSION 4
 #define SR_TILE 16 /* binning tile edge in pixels (upstream BLOCK_X = BLOCK_Y) */
 
 typedef struct SrView {
@@ -144,6 +148,28 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
 int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
                long long binning_capacity, void* image, float* out_color, float* out_depth, float* out_alpha,
                long long* instances_out, void* hip_stream);
+
+/* sr_forward WITHOUT any host wait (the capacity-bounded form of SURVEY.md section 8b: "... or is avoided with a capacity-bounded
+ * workspace"; [EXT] reads num_rendered back in the middle of every forward).  The caller supplies what sr_forward learns by
+ * waiting -- a binning capacity and the longest tile list to expect (`longest_list_hint`: which sort classes to launch: lists up
+ * to 2048 / 4096 / 8192 entries, or all) -- typically what an earlier forward of the same view reported, with headroom.  Both
+ * stages are launched back to back and the call returns; every stage-2 kernel exits on the device if the instance count
+ * exceeds the capacity, and the blend exits if a list is longer than the launched sort classes cover, so a wrong guess never
+ * reads or writes out of bounds -- it leaves the OUTPUTS UNDEFINED.  `*ticket_out` receives a ticket (a pinned status block +
+ * an event recorded behind stage 1, pooled inside the library); the caller MUST redeem it with sr_ticket_wait before it uses
+ * the outputs' gradients (before sr_backward at the latest): it waits for stage 1 of that forward only -- usually long
+ * finished -- and returns the instance count and the longest list; the outputs are valid iff
+ *     instances <= binning_capacity  and  longest_list <= max(2048, the class bound the hint selected).
+ * When they are not, re-run the forward (sr_forward, or sr_forward_async with the reported figures).
+ * sr_ticket_release = sr_ticket_wait without results (a forward whose outputs were dropped).  A ticket is redeemed once. */
+int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
+                     long long binning_capacity, long long longest_list_hint, void* image, float* out_color, float* out_depth,
+                     float* out_alpha, void** ticket_out, void* hip_stream);
+int sr_ticket_wait(void* ticket, long long* instances_out, long long* longest_list_out);
+/* the longest tile list of the calling thread's most recent sr_forward (-1 before the first): the hint of a later
+ * sr_forward_async of the same view */
+long long sr_last_longest_list(void);
+int sr_ticket_release(void* ticket);
 
 /* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero).  `instances` is the capacity the binning
  * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes.
@@ -402,6 +428,12 @@ int sr_debug_layout(int n_splats, int height, int width, long long instances, si
  *           preamble, test, barrier, slot assignment + scatter, barrier, replay, barrier, combine }.
  * Synchronises the device; reset != 0 clears the counters afterwards. */
 int sr_debug_backward_stats(unsigned long long* out16, int reset);
+
+/* Host-synchronisation counters of the forward (process-wide, since load or the last reset):
+ *   out4 = { host waits inside sr_forward (one per call: the instance-count read-back),  sr_forward_async calls (none waits),
+ *            tickets that were redeemed while stage 1 of their forward was still running (the host waited in sr_ticket_wait),
+ *            tickets ever created (the pool's size) }. */
+int sr_debug_counters(long long* out4, int reset);
 
 /* debug = true (SrView.debug): every stage is followed by a stream synchronisation + error check, and a FAILED stage writes
  * the call's arguments to snapshot_fw.dump / snapshot_bw.dump in the working directory before the error is returned -- what

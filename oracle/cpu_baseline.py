@@ -9,7 +9,9 @@ import time
 import torch
 
 
-def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_degree: int, target_seconds: float):
+def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_degree: int, target_seconds: float, keep: dict = None):
+    """`keep` (a dict): when the timed sample covered the WHOLE image, the oracle's outputs and gradients of that run are left
+    in it (`out`, `grads`, `view` = 0): bench.py's `parity` block compares the HIP path with them -- no second oracle run."""
     from oracle import c_oracle
     from oracle import torch_oracle as O
     from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
@@ -20,10 +22,14 @@ def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_de
     gi, gd, ga = make_upstream_grads(height, width)
     gx, gy = (width + 15) // 16, (height + 15) // 16
 
+    last = {}
+
     def timed(window):
         t0 = time.perf_counter()
-        c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=gi, g_depth=gd, g_alpha=ga, tile_window=window, threads=cores)
-        return time.perf_counter() - t0
+        out, grads, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=gi, g_depth=gd, g_alpha=ga, tile_window=window, threads=cores)
+        dt = time.perf_counter() - t0
+        last.update(out=out, grads=grads, window=window)
+        return dt
 
     # calibrate on a centred crop of tile rows, then take the largest crop that fits the time budget:
     # every splat is always preprocessed and binned; only the blended tile window is bounded.
@@ -37,6 +43,8 @@ def run_cpu_baseline(n_splats: int, height: int, width: int, use_sh: bool, sh_de
     y0 = (gy - rows_full) // 2
     window = (0, y0, gx, y0 + rows_full)
     t = timed(window)
+    if keep is not None and rows_full == gy:
+        keep.update(out=last["out"], grads=last["grads"], view=0)
     px = min(height, (y0 + rows_full) * 16) - y0 * 16
     frac = rows_full / gy
     return {"value": n_splats * px * width / t, "unit": "splat*px/s", "cores": cores, "kind": "port",

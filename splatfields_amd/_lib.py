@@ -78,6 +78,12 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sr_forward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
+    "sr_forward_async": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                   C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "sr_ticket_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "sr_ticket_release": (C.c_int, [C.c_void_p]),
+    "sr_last_longest_list": (C.c_longlong, []),
+    "sr_debug_counters": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "sr_backward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SrGrads),
                               C.c_void_p]),
@@ -122,6 +128,7 @@ SYMBOLS = {
 }
 
 PROFILE_STAGES = 7
+SR_VERSION = 4          # include/splatraster.h: the ABI this binding was written against
 SR_NEED_CAPACITY = 2
 SR_RAW_SCALES, SR_RAW_OPACITY, SR_RAW_ROTATIONS, SR_FORWARD_ONLY = 1, 2, 4, 8
 _lib = None
@@ -134,6 +141,10 @@ def bind(path) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
+    got = lib.sr_version()
+    if got != SR_VERSION:   # struct layouts, workspace sizes and buffer contracts belong to a version: never mix them
+        raise RuntimeError(f"{path} implements version {got} of the splatraster ABI, this binding expects {SR_VERSION}: "
+                           "rebuild it with `python -m splatfields_amd.build`")
     return lib
 
 

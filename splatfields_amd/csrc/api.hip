@@ -12,6 +12,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local long long g_last_longest = -1;   // longest tile list of this thread's most recent sr_forward (sr_last_longest_list)
 
 int fail(const std::string& msg) { g_last_error = msg; return 1; }
 
@@ -74,6 +75,40 @@ int get_host_sync(HostSync** out) {
     }
     *out = &h;
     return 0;
+}
+
+// ---- tickets of sr_forward_async ----------------------------------------------------------------------------------------
+// One pinned, coherent 64-byte block (k_scan_small stores the instance count and the longest list into it) and one event
+// (recorded behind stage 1) per forward in flight; pooled per device under a mutex, a few bytes each.
+struct Ticket { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; int dev = 0; };
+std::mutex g_ticket_mutex;
+std::vector<Ticket*> g_ticket_free[64];
+// diagnostics (sr_debug_counters): [0] host waits inside sr_forward, [1] sr_forward_async calls, [2] ticket redemptions that
+// found stage 1 still running (the host had to wait), [3] tickets ever created
+std::atomic<long long> g_counters[4];
+
+int ticket_acquire(Ticket** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail("hipGetDevice failed");
+    {
+        std::lock_guard<std::mutex> lock(g_ticket_mutex);
+        if (!g_ticket_free[dev].empty()) { *out = g_ticket_free[dev].back(); g_ticket_free[dev].pop_back(); return 0; }
+    }
+    Ticket* t = new Ticket;
+    t->dev = dev;
+    if (hipHostMalloc(reinterpret_cast<void**>(&t->pinned), 64, hipHostMallocCoherent) != hipSuccess &&
+        hipHostMalloc(reinterpret_cast<void**>(&t->pinned), 64, hipHostMallocDefault) != hipSuccess) { delete t; return fail("hipHostMalloc failed"); }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, t->pinned, 0) != hipSuccess) { hipHostFree(t->pinned); delete t; return fail("hipHostGetDevicePointer failed"); }
+    t->pinned_dev = static_cast<uint32_t*>(dp);
+    if (hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) { hipHostFree(t->pinned); delete t; return fail("hipEventCreate failed"); }
+    g_counters[3].fetch_add(1, std::memory_order_relaxed);
+    *out = t;
+    return 0;
+}
+void ticket_recycle(Ticket* t) {
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    g_ticket_free[t->dev].push_back(t);
 }
 
 // 0 = choose the backward blend kernel by footprint, 1 = pixel-per-lane, 2 = entry-per-lane (sr_set_backward_kernel)
@@ -228,12 +263,14 @@ int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
 
 // hs != nullptr: the instance count / longest list were copied to hs->pinned and hs->ev recorded; the host waits for
 // them after launching the scatter (the GPU keeps working) and then launches only the sort classes that are needed.
+// hs == nullptr: nobody waits; `max_len` = the longest list the sort classes must cover (< 0: launch every class).
 int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, const sr::Binning& b,
-                  const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, HostSync* hs, hipStream_t st) {
+                  const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, HostSync* hs, long long max_len,
+                  hipStream_t st) {
     { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
     SR_TRY(after_launch(view, st, "emit"));
-    long long max_len = -1;
     if (hs) {
+        g_counters[0].fetch_add(1, std::memory_order_relaxed);
         SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));
         max_len = (long long)hs->pinned[1];
         // the binning buffer is too small: the scatter just launched exits on its own, and nothing else of stage 2 is worth
@@ -287,9 +324,10 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
     SR_TRY(get_host_sync(&hs));
     SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));   // k_scan_small stores the two counters into hs->pinned
     SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
-    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, st));  // waits inside, GPU busy
+    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, -1, st));  // waits inside, GPU busy
     const long long total = (long long)hs->pinned[0];
     *instances_out = total;
+    g_last_longest = (long long)hs->pinned[1];
     return total > binning_capacity ? SR_NEED_CAPACITY : 0;
 }
 
@@ -307,7 +345,68 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     sr::carve_binning(binning, instances, &b);
     sr::carve_image(image, v.H, v.W, &im);
-    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, st);
+    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, -1, st);
+}
+
+int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
+                     long long binning_capacity, long long longest_list_hint, void* image, float* out_color, float* out_depth,
+                     float* out_alpha, void** ticket_out, void* hip_stream) {
+    SR_TRY(validate(view, splats));
+    g_call = CallContext{view, splats, "snapshot_fw.dump"};
+    if (!geom || !binning || !image || !out_color || !out_depth || !ticket_out || (splats->count > 0 && !radii)) return fail("null buffer");
+    if (binning_capacity < 0 || binning_capacity >= (1ll << 32)) return fail("binning capacity out of range");
+    if (longest_list_hint < 0) return fail("longest_list_hint must be >= 0");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const sr::ViewK v = make_view(view);
+    const sr::SplatsK s = make_splats(splats);
+    sr::Geom g; sr::Binning b; sr::Image im;
+    sr::carve_geom(geom, s.N, v.H, v.W, &g);
+    sr::carve_binning(binning, binning_capacity, &b);
+    sr::carve_image(image, v.H, v.W, &im);
+    // the sort classes the hint asks for: lists up to 2048 / 4096 / 8192 entries, or all of them
+    const long long covered = longest_list_hint <= 2048 ? 2048 : longest_list_hint <= 4096 ? 4096 : longest_list_hint <= 8192 ? 8192 : -1;
+    b.sorted_up_to = covered < 0 ? 0xffffffffu : (uint32_t)covered;
+    Ticket* t = nullptr;
+    SR_TRY(ticket_acquire(&t));
+    t->pinned[0] = 0u; t->pinned[1] = 0u;
+    int rc = launch_stage1(view, v, s, g, radii, t->pinned_dev, st);
+    if (!rc) rc = check_hip(hipEventRecord(t->ev, st), "record");
+    if (!rc) rc = launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, covered, st);
+    if (rc) {   // nothing of this call may still write the block when it is handed out again
+        (void)hipStreamSynchronize(st);
+        ticket_recycle(t);
+        return rc;
+    }
+    g_counters[1].fetch_add(1, std::memory_order_relaxed);
+    *ticket_out = t;
+    return 0;
+}
+
+int sr_ticket_wait(void* ticket, long long* instances_out, long long* longest_list_out) {
+    if (!ticket) return fail("null ticket");
+    Ticket* t = static_cast<Ticket*>(ticket);
+    const hipError_t q = hipEventQuery(t->ev);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        g_counters[2].fetch_add(1, std::memory_order_relaxed);
+    }
+    const int rc = check_hip(hipEventSynchronize(t->ev), "wait for the ticket of sr_forward_async");
+    if (instances_out) *instances_out = (long long)t->pinned[0];
+    if (longest_list_out) *longest_list_out = (long long)t->pinned[1];
+    ticket_recycle(t);
+    return rc;
+}
+
+long long sr_last_longest_list(void) { return g_last_longest; }
+
+int sr_ticket_release(void* ticket) {
+    return sr_ticket_wait(ticket, nullptr, nullptr);
+}
+
+int sr_debug_counters(long long* out4, int reset) {
+    if (!out4) return fail("null pointer in sr_debug_counters");
+    for (int i = 0; i < 4; ++i) out4[i] = reset ? g_counters[i].exchange(0, std::memory_order_relaxed) : g_counters[i].load(std::memory_order_relaxed);
+    return 0;
 }
 
 namespace {

@@ -44,6 +44,10 @@ __global__ void __launch_bounds__(kBlock) k_count_tiles(const ViewK v, int N, co
     __shared__ float4 s_r0[kBlock], s_r1[kBlock];   // ellipse of each splat, prepared for the tile_reached test
     __shared__ uint32_t s_scan[8];
     for (int t = 4 * threadIdx.x; t < ch.tiles_padded; t += 4 * kBlock) *reinterpret_cast<uint4*>(&s_hist[t]) = make_uint4(0u, 0u, 0u, 0u);   // tiles_padded % 64 == 0
+    // the per-thread path below adds into s_hist before the first workgroup barrier of the sub-batch loop: without this one a
+    // wavefront still clearing its share of the table could overwrite another wavefront's increment (a tile count comes out
+    // low, and k_emit's piece of that tile segment then overflows into the neighbouring chunk's)
+    __syncthreads();
     const int base_chunk = (int)blockIdx.x / ch.slices, slice = (int)blockIdx.x % ch.slices;
     const int sb0 = base_chunk * ch.sub_per_chunk, sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
     // (Requesting the inputs of four sub-batches at a time, as k_emit does, was measured here in round 4: the scan stage went

@@ -487,8 +487,14 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
     if (bmax == 0) return;   // uniform: empty list, or no pixel of the tile blended anything
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
     const uint32_t* qms = b.qmask + start;
-    BwdEntry cur = load_entry(g, ids[max(hi - 1 - tid, 0)], qms, hi - 1 - tid);
+#ifndef SR_BWD_EARLY_PIX
+#define SR_BWD_EARLY_PIX 1   // 1: the per-pixel inputs are requested BETWEEN the splat-index load and the record gather that depends
+#endif                       //    on it (one memory round trip less in every tile's preamble); 0: behind the gather (rounds 2-4)
+    const uint32_t id_first = ids[max(hi - 1 - tid, 0)];
     uint32_t id_next = ids[max(hi - kChunk - 1 - tid, 0)];   // its splat index: loaded another chunk earlier
+#if !SR_BWD_EARLY_PIX
+    BwdEntry cur = load_entry(g, id_first, qms, hi - 1 - tid);
+#endif
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -511,6 +517,9 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
         // no barrier here: the first readers of these tables (replay) sit behind the two barriers of the first chunk
     }
+#if SR_BWD_EARLY_PIX
+    BwdEntry cur = load_entry(g, id_first, qms, hi - 1 - tid);
+#endif
 
     const int k = lane >> 4, nl = lane & 15;
     const uint32_t lt_mask = (1u << (lane & 31)) - 1u;   // earlier entries of this thread's block

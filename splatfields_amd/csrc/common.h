@@ -113,6 +113,10 @@ struct Binning {
                          //     backward blend for the list entries in front of the stop of the tile's last pixel, tested by
                          //     k_preprocess_backward: unreached slots are neither written nor read
     uint32_t capacity;   // instances the arrays above were carved for; stage-2 kernels exit if total > capacity
+    uint32_t sorted_up_to;   // longest tile list the launched sort classes cover (0xffffffff: every class the lists need was
+                             // launched -- the host knew the longest list).  sr_forward_async launches the classes a HINT asks for
+                             // without waiting for the real figure: k_render_forward exits if a longer list exists (its ids were
+                             // never written), and the caller finds out when it redeems the ticket
 };
 
 struct Image {
@@ -172,6 +176,7 @@ inline size_t carve_binning(void* base, long long R, Binning* b) {
     t.qmask = c.take<uint32_t>(r);
     t.reached = c.take<uint8_t>(r);
     t.capacity = (uint32_t)(R > 0 ? R : 0);
+    t.sorted_up_to = 0xffffffffu;
     if (b) *b = t;
     return align_up(c.off, 256);
 }

@@ -500,11 +500,17 @@ struct ResFieldK { SrResFieldJob job[SR_RESFIELD_MAX_JOBS]; const long long* fra
 
 constexpr int kRfPerBlock = kBlock * 4;   // elements of W per workgroup
 
+// frame index as the reference's `mat[frame_id]` reads it: indices in [-capacity, 0) wrap (Python indexing; general_mlp.py's
+// host-side check wraps the same way), everything else outside [0, capacity) is an error
+__device__ __forceinline__ long long resfield_frame(long long f, int capacity) {
+    return (f < 0 && f >= -(long long)capacity) ? f + (long long)capacity : f;
+}
+
 __global__ void __launch_bounds__(kBlock) k_resfield_compose(const ResFieldK P) {
     const SrResFieldJob J = P.job[blockIdx.y];
     const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
     if (4 * j4 >= J.count) return;
-    const long long f = *P.frame;
+    const long long f = resfield_frame(*P.frame, J.capacity);
     if (f < 0 || f >= (long long)J.capacity) {
         // the reference's `mat[frame_id]` raises IndexError here; a kernel cannot, and reading weights_t out of bounds would
         // compose garbage silently: poison the weights instead, so that the network's outputs are NaN from this step on
@@ -538,7 +544,7 @@ __global__ void __launch_bounds__(kBlock) k_resfield_backward(const ResFieldK P)
     if (blockIdx.x * kRfPerBlock >= J.count) return;   // whole workgroup
     const int j4 = blockIdx.x * kBlock + (int)threadIdx.x;
     const bool in = 4 * j4 < J.count;
-    const long long f_raw = *P.frame;
+    const long long f_raw = resfield_frame(*P.frame, J.capacity);
     const bool f_ok = f_raw >= 0 && f_raw < (long long)J.capacity;   // out of range: the forward poisoned W_eff with NaN (above);
     const long long f = f_ok ? f_raw : 0;                             //   here: no out-of-bounds read, NaN gradients
     const float* coeff = J.weights_t + (size_t)f * J.rank;
@@ -566,7 +572,7 @@ __global__ void __launch_bounds__(kBlock) k_resfield_backward(const ResFieldK P)
 __global__ void __launch_bounds__(kBlock) k_resfield_finish(const ResFieldK P) {
     const SrResFieldJob J = P.job[blockIdx.x];
     if (!J.d_weights_t) return;
-    const long long f = *P.frame;
+    const long long f = resfield_frame(*P.frame, J.capacity);
     const int nb = (J.count + kRfPerBlock - 1) / kRfPerBlock;
     for (int i = threadIdx.x; i < J.capacity * J.rank; i += kBlock) {
         float v = 0.0f;

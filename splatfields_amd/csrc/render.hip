@@ -102,10 +102,14 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     __shared__ uint16_t s_qm[SR_FWD_BUFS][kB];   // quad-reach mask of every staged entry (quadmask.h)
     __shared__ uint32_t s_live[2][4];            // per batch parity and wavefront: does it still have accumulating pixels?
 #if SR_FWD_QUADS
-    __shared__ uint8_t s_idx[4][4][kB];          // per wavefront and quad of its sub-tile: the batch entries that reach the quad
+    __shared__ uint8_t s_idx[4][4][kB + 4];      // per wavefront and quad of its sub-tile: the batch entries that reach the quad
+                                                 // (+ 4: the pipelined walk reads its index two trips ahead)
 #endif
+#ifndef SR_FWD_PIPE
+#define SR_FWD_PIPE 1   // 1: the trip loop reads the index two trips and the record one trip ahead (software pipeline, two copies of
+#endif                  //    the body so that no register is copied); 0: index -> record -> arithmetic serially in every trip (round 4)
 
-    if (g.total[0] > b.capacity) return;  // uniform: see sr_forward
+    if (g.total[0] > b.capacity || g.total[1] > b.sorted_up_to) return;  // uniform: see sr_forward / sr_forward_async
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
@@ -227,9 +231,53 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #endif
             wave_lds_fence();
             const uint32_t my_len = qrow == 0 ? qlen[0] : qrow == 1 ? qlen[1] : qrow == 2 ? qlen[2] : qlen[3];
-            const uint32_t n_trip = max(max(qlen[0], qlen[1]), max(qlen[2], qlen[3]));
+            const uint32_t n_trip = (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(qlen[0], qlen[1]), max(qlen[2], qlen[3])));
             const uint8_t* my_idx = &s_idx[wave][qrow][0];
             const uint32_t posb = base - start;
+#if SR_FWD_PIPE
+            // One trip = four entries (one per row of 16 lanes): index (1 byte) -> record (40 bytes) -> ~20 dependent VALU
+            // instructions.  Read serially that is two LDS round trips in front of every trip's arithmetic; here the index of
+            // trip i + 2 and the record of trip i + 1 are requested before trip i's arithmetic starts (LDS returns in order, so
+            // the waits the compiler places count exactly what is still outstanding).  Two copies of the body alternate two
+            // register sets: nothing is copied.  Indices past a row's list are stale bytes (< 256: a valid slot of the staging
+            // area) and are masked by `i < my_len` as before.
+            struct Rec { float2 ef; float4 r1, r2; };
+            auto fetch = [&](uint32_t e) { Rec r; r.ef = *reinterpret_cast<const float2*>(&s_r0[buf][e]); r.r1 = s_r1[buf][e]; r.r2 = s_r2[buf][e]; return r; };
+            auto trip = [&](uint32_t i, uint32_t e, const Rec& rc) -> bool {   // true: every pixel of the wavefront has stopped
+                float G0, K;
+                pair_alpha_row(Yf, rc.ef.x, rc.ef.y, rc.r1.y, rc.r1.z, rc.r1.w, G0, K);
+                const float alpha = fminf(kAlphaMax, pair_alpha_px(Xf, rc.r1.x, G0, K));
+                const float test_T = T * (1.0f - alpha);
+                const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & __builtin_amdgcn_ballot_w64(i < my_len) & livem;
+                const uint64_t stopm = __builtin_amdgcn_ballot_w64(test_T < kTStop) & hitm;
+                const uint64_t blendm = hitm ^ stopm;  // stop implies hit
+                livem &= ~stopm;
+                const float w = mask_select(blendm, alpha * T, 0.0f);
+                Cr = fmaf(rc.r2.x, w, Cr); Cg = fmaf(rc.r2.y, w, Cg); Cb = fmaf(rc.r2.z, w, Cb); D = fmaf(rc.r2.w, w, D);
+                T = mask_select(blendm, test_T, T);
+                if (stopm != 0ull) {   // rare: once per pixel at most
+                    last = mask_select(stopm, posb + e, last);
+                    return livem == 0ull;
+                }
+                return false;
+            };
+            if (n_trip != 0u) {
+                uint32_t ea = my_idx[0], eb = my_idx[1];
+                Rec ra = fetch(ea);
+#pragma unroll 1
+                for (uint32_t i = 0;;) {
+                    const Rec rb = fetch(eb);                 // trip i + 1
+                    const uint32_t ea_n = my_idx[i + 2];
+                    if (trip(i, ea, ra)) break;
+                    if (++i >= n_trip) break;
+                    ra = fetch(ea_n);                         // trip i + 1 (after the increment): i + 2 of the loop top
+                    const uint32_t eb_n = my_idx[i + 2];
+                    if (trip(i, eb, rb)) break;
+                    if (++i >= n_trip) break;
+                    ea = ea_n; eb = eb_n;
+                }
+            }
+#else
             for (uint32_t i = 0; i < n_trip; ++i) {
                 const uint32_t e = my_idx[i];                      // rows past their list read a stale index: masked below
                 const float2 ef = *reinterpret_cast<const float2*>(&s_r0[buf][e]);   // (E0, F0)
@@ -250,6 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     if (livem == 0ull) break;
                 }
             }
+#endif
         }
 #else
         if (livem != 0ull) {

@@ -60,6 +60,49 @@ def set_depth_gradient(enabled: bool) -> bool:
 def depth_gradient_enabled() -> bool:
     return _DEPTH_GRADIENT
 
+# ---- host-synchronisation-free forward (include/splatraster.h: sr_forward_async) ------------------------------------------
+# sr_forward waits, in the middle of every forward, for the instance count of the view ([EXT] does the same: its num_rendered
+# read-back).  What the host needs the figure for -- the size of the binning buffer and which sort
+# classes to launch -- is known from the LAST render of the same camera with the same number of splats, so that forward is
+# launched without waiting (both figures with 25 % headroom; the kernels exit on the device when a guess was too small) and
+# the wait moves to where the figures are needed: the backward -- by then long behind stage 1 of that forward -- or
+# `resolve_pending()`.  A training loop renders its cameras over and over, so after the first epoch no forward waits; with
+# several views per step the V forwards are enqueued back to back.
+# A wrong guess (the same view grew by more than 25 % since its last render) leaves the outputs of that forward undefined and
+# raises RasterizerOverflow when the ticket is redeemed -- at the backward at the latest, i.e. before any gradient leaves;
+# nothing was applied, the capacities have been corrected, re-running the step succeeds.  The step functions of
+# splatfields_amd/view_parallel.py and render.py redeem the tickets BEFORE their backward and re-render transparently.
+# First renders of a camera (or of a new splat count: after densification) always take the waiting path.
+# SPLATRASTER_ASYNC=0 / set_async_forward(False): every forward waits (rounds 1-4).
+_ASYNC = os.environ.get("SPLATRASTER_ASYNC", "1") not in ("0", "false", "False", "off")
+_LIST_HEADROOM = 1.25
+
+
+class RasterizerOverflow(RuntimeError):
+    """An asynchronously launched forward (sr_forward_async) met more tile-splat instances, or a longer tile list, than the
+    last render of that view had promised: its outputs are undefined.  The estimates have been corrected; re-run the step."""
+
+
+def set_async_forward(enabled: bool) -> bool:
+    """Launch forwards of cameras seen before without waiting for their instance count (default) or wait in every forward.
+    Returns the previous setting."""
+    global _ASYNC
+    prev, _ASYNC = _ASYNC, bool(enabled)
+    return prev
+
+
+def async_forward_enabled() -> bool:
+    return _ASYNC
+
+
+def host_sync_counters(reset: bool = False) -> dict:
+    """Process-wide counters of the library (sr_debug_counters): how many forwards waited on the host, how many did not."""
+    out = (C.c_longlong * 4)()
+    _lib.check(_lib.load().sr_debug_counters(out, 1 if reset else 0))
+    return {"forward_host_waits": int(out[0]), "async_forwards": int(out[1]), "tickets_waited_for": int(out[2]),
+            "tickets_created": int(out[3])}
+
+
 _BWD_KERNELS = {None: 0, "auto": 0, "wave": 1, "quads": 2, "mfma": 2}   # "mfma": the name rounds 2-3 gave the entry-per-lane kernel
 
 
@@ -90,7 +133,89 @@ def _round_capacity(instances: int) -> int:
 # The library takes concurrent calls from host threads that render on their own streams (include/splatraster.h); these two
 # module-level estimates are the only state the facade shares between them: updated under a lock (read-modify-write of a max).
 import threading
+import weakref
 _CAPACITY_LOCK = threading.Lock()
+_TLS = threading.local()   # .pending: this host thread's forwards whose ticket has not been redeemed yet
+
+
+def _record_view(view, n: int, instances: int, longest: int) -> None:
+    """what the next render of this camera with this splat count may assume (kept on the cached view pack)"""
+    if longest >= 0:
+        if len(view.seen) > 64:   # densification changes the count thousands of times in a long run
+            view.seen.clear()
+        view.seen[n] = (int(instances), int(longest))
+
+
+class _Pending:
+    """One forward launched by sr_forward_async: its ticket and what it was promised."""
+
+    def __init__(self, lib, ticket, capacity: int, covered: int, view, n: int, key, rkey):
+        self.lib, self.ticket, self.capacity, self.covered = lib, ticket, int(capacity), int(covered)
+        self.view, self.n, self.key, self.rkey = view, n, key, rkey
+        self.instances = None
+        self.error = None
+        # weak: a forward whose outputs are dropped without a backward (evaluation code that forgot no_grad) must not pin its
+        # ticket -- the autograd ctx owns this object, and __del__ hands the ticket back
+        lst = getattr(_TLS, "pending", None)
+        if lst is None:
+            lst = _TLS.pending = []
+        if len(lst) > 64:
+            lst[:] = [r for r in lst if r() is not None]
+        lst.append(weakref.ref(self))
+
+    def resolve(self) -> int:
+        """Redeems the ticket (waits for stage 1 of that forward if it is still running); returns the instance count or raises
+        RasterizerOverflow.  Idempotent."""
+        if self.ticket is not None:
+            ticket, self.ticket = self.ticket, None
+            inst, longest = C.c_longlong(0), C.c_longlong(0)
+            rc = self.lib.sr_ticket_wait(ticket, C.byref(inst), C.byref(longest))
+            lst = getattr(_TLS, "pending", None)
+            if lst is not None:
+                lst[:] = [r for r in lst if r() is not None and r() is not self]
+            _lib.check(rc)
+            self.instances = int(inst.value)
+            instances, longest = int(inst.value), int(longest.value)
+            with _CAPACITY_LOCK:
+                _CAPACITY[self.key] = max(_CAPACITY.get(self.key, 0), _round_capacity(instances))
+                _INSTANCES_PER_SPLAT[self.rkey] = max(_INSTANCES_PER_SPLAT.get(self.rkey, 0.0), instances / max(self.n, 1))
+            _record_view(self.view, self.n, instances, longest)
+            global LAST_INSTANCES
+            LAST_INSTANCES = instances
+            if instances > self.capacity or longest > max(self.covered, 2048):
+                self.error = RasterizerOverflow(
+                    f"the forward of this view was launched without waiting for its instance count (sr_forward_async) for at most "
+                    f"{self.capacity} tile-splat instances and tile lists of up to {max(self.covered, 2048)} entries, but the view has "
+                    f"{instances} instances and a list of {longest}: its outputs are undefined.  Nothing has been applied and the "
+                    f"estimates are corrected: re-run the step (or splatfields_amd.rasterizer.set_async_forward(False))")
+        if self.error is not None:
+            raise self.error
+        return self.instances
+
+    def __del__(self):   # a forward whose outputs were dropped without a backward: hand the ticket back
+        t, self.ticket = getattr(self, "ticket", None), None
+        if t is not None:
+            try:
+                self.lib.sr_ticket_release(t)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+
+
+def resolve_pending() -> None:
+    """Redeems the tickets of every forward this host thread launched asynchronously and has not checked yet (each waits for
+    stage 1 of its forward only).  Raises RasterizerOverflow if one of them overflowed -- after all have been redeemed, so the
+    caller can simply re-render."""
+    err = None
+    for ref in list(getattr(_TLS, "pending", None) or []):
+        p = ref()
+        if p is None:
+            continue
+        try:
+            p.resolve()
+        except RasterizerOverflow as e:
+            err = err or e
+    if err is not None:
+        raise err
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -153,6 +278,7 @@ class _ViewPack:
             raise RuntimeError("viewmatrix and projmatrix must hold 16 elements ([4,4] or [1,4,4])")
         if self.campos.numel() != 3 or self.bg.numel() != 3:
             raise RuntimeError("campos and bg must hold 3 elements")
+        self.seen = {}   # splat count -> (instances, longest tile list) of the last render of this camera (sr_forward_async)
         self.struct = _lib.SrView(
             int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
             float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), int(bool(rs.prefiltered)),
@@ -210,6 +336,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise RuntimeError("with shs_rest, shs must be [N,1,3] (dc) and shs_rest [N,15,3]")
             sh_coeffs = 16
 
+        if slice_hook is not None:
+            # checked here, not in the backward: an exception raised inside the autograd thread of ONE rank would leave the
+            # other ranks waiting in their collectives
+            if cov_c is not None:
+                raise ValueError("slice_hook requires scales / rotations inputs (cov3D_precomp is not supported in the sliced backward)")
+            if rest_c is not None:
+                raise ValueError("slice_hook requires the concatenated shs tensor (shs_rest is not supported in the sliced backward)")
+            if sh_c is not None and color_grad_sink is None:
+                raise ValueError("slice_hook requires color_grad_sink on the SH path (the sliced backward hands over colour gradients)")
         view = _ViewPack.get(raster_settings, dev, sh_coeffs)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -234,6 +369,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             depth.zero_()
             alpha.zero_()
             ctx.instances = 0
+            ctx.pending = None
             ctx.save_for_backward()
             return color, radii, depth, alpha
 
@@ -250,10 +386,28 @@ class _RasterizeGaussians(torch.autograd.Function):
             with _CAPACITY_LOCK:
                 ratio = _INSTANCES_PER_SPLAT.get((dev.index, H, W))
                 capacity = _CAPACITY.get(key) or (max(4 * n, 1 << 16) if ratio is None else _round_capacity(int(ratio * n)))
+            rkey = (dev.index, H, W)
+            before = view.seen.get(n) if (_ASYNC and not (int(raw_params) & _lib.SR_FORWARD_ONLY)) else None
+            if before is not None and _round_capacity(before[0]) <= capacity:
+                # this camera was rendered with this splat count before: launch without waiting (see _ASYNC above)
+                binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
+                hint = int(before[1] * _LIST_HEADROOM) + 1
+                covered = 2048 if hint <= 2048 else 4096 if hint <= 4096 else 8192 if hint <= 8192 else 1 << 62
+                ticket = C.c_void_p()
+                _lib.check(lib.sr_forward_async(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
+                                                capacity, hint, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha),
+                                                C.byref(ticket), stream))
+                ctx.pending = _Pending(lib, ticket, capacity, covered, view, n, key, rkey)
+                ctx.instances = None
+                ctx.capacity = capacity
+                ctx.view_pack = view
+                ctx.save_for_backward(means3D_c, opac_c, sc_c, rot_c, cov_c, sh_c, col_c, radii, geom, binning, image, rest_c)
+                return color, radii, depth, alpha
             binning = torch.empty(lib.sr_binning_bytes(capacity, H, W), dtype=torch.uint8, device=dev)
             status = lib.sr_forward(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
                                     capacity, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha), C.byref(inst), stream)
             instances = int(inst.value)
+            _record_view(view, n, instances, int(lib.sr_last_longest_list()))
             if status == _lib.SR_NEED_CAPACITY:
                 # first call for this size, or the cloud grew: re-run stage 2 with a buffer that fits
                 capacity = _round_capacity(instances)
@@ -266,10 +420,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _CAPACITY[key] = max(_CAPACITY.get(key, 0), _round_capacity(instances))
                 if len(_CAPACITY) > 4096:  # a long training run changes the splat count thousands of times
                     _CAPACITY.clear()
-                rkey = (dev.index, H, W)
                 _INSTANCES_PER_SPLAT[rkey] = max(_INSTANCES_PER_SPLAT.get(rkey, 0.0), instances / max(n, 1))
         global LAST_INSTANCES
         LAST_INSTANCES = instances
+        ctx.pending = None
         ctx.instances = instances
         ctx.capacity = capacity
         ctx.view_pack = view
@@ -283,6 +437,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if n == 0:
             return (None,) * 13
         lib = _lib.load()
+        if ctx.pending is not None:
+            # the forward did not wait for its instance count: redeem its ticket now (stage 1 of that forward is long over;
+            # raises RasterizerOverflow if the capacity it was launched with did not hold -- before any gradient is produced)
+            ctx.instances = ctx.pending.resolve()
         means3D, opac, sc, rot, cov, sh, col, radii, geom, binning, image, sh_rest = ctx.saved_tensors
         dev = means3D.device
         H, W = int(rs.image_height), int(rs.image_width)
@@ -299,8 +457,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # sliced mode (view-parallel exchange, splatfields_amd/view_parallel.py): the gradients are written into the HOOK's
             # buffers, slice by slice, and the hook is called behind every slice's launch -- it starts that slice's collectives
             # while the next slice is computed.  Autograd gets no gradient for these inputs (the hook's owner sets `.grad`).
-            if cov is not None or sh_rest is not None or (sh is not None and sink is None):
-                raise RuntimeError("slice_hook: scale / rotation inputs, and colour gradients (color_grad_sink) on the SH path")
+            assert cov is None and sh_rest is None and (sh is None or sink is not None)   # validated in forward
             hb = hook.buffers(n)
             d_means3D, d_sc, d_rot, d_opac, d_col = hb["means3D"], hb["scales"], hb["rotations"], hb["opacities"], hb["colors"]
             d_means2D, d_cov, d_sh, d_rest = new(n, 3), None, None, None

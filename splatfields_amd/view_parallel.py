@@ -103,6 +103,21 @@ class _Window:
         return False
 
 
+def _checked(render_fn: Callable):
+    """``render_fn()`` launches a forward -- without waiting for its instance count when the camera was rendered before
+    (rasterizer.py: sr_forward_async) -- and returns its outputs.  The ticket is redeemed HERE, before the caller
+    back-propagates: a forward whose capacity guess did not hold is re-rendered (the estimates are corrected by then), so the
+    step functions never see RasterizerOverflow in the middle of an autograd pass -- and a rank never re-issues collectives."""
+    from . import rasterizer as rz
+    out = render_fn()
+    try:
+        rz.resolve_pending()
+    except rz.RasterizerOverflow:
+        out = render_fn()
+        rz.resolve_pending()
+    return out
+
+
 def _nbytes(t: torch.Tensor) -> float:
     return float(t.numel() * t.element_size())
 
@@ -340,7 +355,9 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     backward runs in that many splat ranges, and the exchange of a finished range -- all-gather of its colour gradients, one
     grouped in-place all-reduce of its geometric gradients (no packing copy) -- is issued right behind it, so it overlaps the
     remaining ranges and the SH-gradient rebuild of earlier ones.  Results are identical to the unsliced step (same kernels
-    per splat, same collectives per row)."""
+    per splat, same collectives per row).  Loss terms of ``backward_fn`` that reach the parameters OUTSIDE the rasterizer
+    (regularisers on scales / opacities / SH, ...) are supported in both forms: their gradients are summed over the ranks by one
+    extra packed all-reduce and added (every rank must run the same ``backward_fn``, as in any data-parallel step)."""
     import math
     from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from . import sh as shmod
@@ -369,9 +386,9 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
             tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
             projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
         sink = []
-        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+        color, radii, depth, alpha = _checked(lambda: GaussianRasterizer(rs).forward_ex(
             means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
-            shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink)
+            shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink))
         # the rasterizer's backward accumulates the 4 small gradients (incl. the view-direction term in means3D) and hands
         # over the clamp-masked colour gradient instead of writing 192 B/splat of SH gradient
         backward_fn(vi, color, depth, alpha)
@@ -379,6 +396,9 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
     for k in names:
         if params[k].grad is None:
             params[k].grad = torch.zeros_like(params[k])
+    # an SH gradient that did not come through the rasterizer (it hands over colour gradients here): an SH regulariser of
+    # backward_fn; summed over the ranks and added to the rebuilt gradient below
+    sh_extra = params["shs"].grad
     dcol_local = dcol_views[0][None] if len(dcol_views) == 1 else torch.stack(dcol_views)
     campos_all = _campos_of(cams, dev)
     if _exchange(world):
@@ -395,14 +415,24 @@ def sh_gather_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_fn
             flat, views = pack_gradients([params[k].grad for k in names])
             reduce_work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
             ExchangeStats.note("all_reduce", _nbytes(flat), world)
+            extra_work = None
+            if sh_extra is not None:
+                sh_extra = sh_extra.detach().to(torch.float32).contiguous()
+                extra_work = dist.all_reduce(sh_extra, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                ExchangeStats.note("all_reduce", _nbytes(sh_extra), world)
             gather_work.wait()
             with _Window(dev, inner=True):
-                params["shs"].grad = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
+                d_shs = shmod.sh_backward(means3D, shs, campos_used, dcol_all, sh_degree, want_shs=True)
             reduce_work.wait()
+            if extra_work is not None:
+                extra_work.wait()
         for k, v in zip(names, views):
             params[k].grad = v
     else:
-        params["shs"].grad = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
+        d_shs = shmod.sh_backward(means3D, shs, campos_all, dcol_local, sh_degree, want_shs=True)
+    if sh_extra is not None:
+        d_shs = d_shs + sh_extra.to(d_shs.dtype)
+    params["shs"].grad = d_shs if d_shs.dtype == params["shs"].dtype else d_shs.to(params["shs"].dtype)
 
 
 def _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_modifier, rank, world, group, slices, vi) -> None:
@@ -421,9 +451,9 @@ def _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_mod
         projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
     hook = _SlicedGatherHook(slices, world, group, dev)
     sink = []
-    color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+    color, radii, depth, alpha = _checked(lambda: GaussianRasterizer(rs).forward_ex(
         means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
-        shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink, slice_hook=hook)
+        shs=shs, scales=params["scales"], rotations=params["rotations"], color_grad_sink=sink, slice_hook=hook))
     campos_all = _campos_of(cams, dev)          # gathered[r] is view r (one view per rank: V == world)
     d_shs = torch.empty_like(shs, dtype=torch.float32)
     backward_fn(vi, color, depth, alpha)    # blend, then per slice: per-splat backward + hook.on_slice (collectives issued)
@@ -434,6 +464,17 @@ def _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_mod
         from .rasterizer import slice_ranges
         for j, (lo, hi) in enumerate(slice_ranges(means3D.shape[0], slices)):
             hook.on_slice(j, lo, hi)
+    # Gradients that reached the leaves OUTSIDE the rasterizer (scale / opacity regularisers, any extra loss term of
+    # backward_fn): the rasterizer's backward handed autograd nothing for these inputs (its part sits in the hook's buffers and is
+    # already on the wire), so whatever `.grad` holds now is that extra part.  It is summed over the ranks by one packed
+    # all-reduce of its own and added below -- the unsliced path gets the same result through autograd's accumulation.  Every
+    # rank runs the same backward_fn, so every rank finds the same set of extras (the usual data-parallel assumption).
+    extra_names = [k for k in names + ["shs"] if params[k].grad is not None]
+    extra_work, extra_views = None, []
+    if extra_names:
+        flat, extra_views = pack_gradients([params[k].grad.detach().to(torch.float32) for k in extra_names])
+        extra_work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        ExchangeStats.note("all_reduce", _nbytes(flat), world)
     m_det, s_det = means3D.detach(), shs.detach()
     for lo, hi, gathered, gw, rw in hook.pending:
         gw.wait()
@@ -441,11 +482,17 @@ def _sh_gather_step_sliced(params, cams, bg, sh_degree, backward_fn, scaling_mod
             shmod.sh_backward(m_det[lo:hi], s_det[lo:hi], campos_all, gathered, sh_degree, want_shs=True, out=d_shs[lo:hi])
     for _, _, _, _, rw in hook.pending:
         rw.wait()
+    if extra_work is not None:
+        extra_work.wait()
     if hook.window is not None:
         hook.window.__exit__(None, None, None)
-    for k in names:
-        params[k].grad = hook.buf[k].view(params[k].shape)
-    params["shs"].grad = d_shs
+    out = {k: hook.buf[k].view(params[k].shape) for k in names}
+    out["shs"] = d_shs
+    for k, v in zip(extra_names, extra_views):
+        out[k] += v.view(out[k].shape)
+    for k, g in out.items():
+        # the kernels compute in fp32; a parameter of another dtype gets its gradient in its own (as the unsliced path does)
+        params[k].grad = g if g.dtype == params[k].dtype else g.to(params[k].dtype)
 
 
 _CAMPOS_CACHE: dict = {}
@@ -551,9 +598,9 @@ def sh_sharded_step(params: dict, cams: Sequence, bg, sh_degree: int, backward_f
             image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(cam.FoVx * 0.5),
             tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
             projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
-        color, radii, depth, alpha = GaussianRasterizer(rs).forward_ex(
+        color, radii, depth, alpha = _checked(lambda: GaussianRasterizer(rs).forward_ex(
             means3D=means3D, means2D=torch.zeros_like(means3D, requires_grad=True), opacities=params["opacities"],
-            colors_precomp=cols, scales=params["scales"], rotations=params["rotations"])
+            colors_precomp=cols, scales=params["scales"], rotations=params["rotations"]))
         backward_fn(vi, color, depth, alpha)
         g = cols.grad if cols.grad is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
         dcol_send[:, slot].reshape(world * shard, 3)[:n].copy_(g) if k == 1 else \
@@ -602,10 +649,15 @@ def view_parallel_step(params: List[torch.Tensor], views: Sequence, render_loss:
     for p in params:
         p.grad = None
     mine = shard_views(views, rank, world)
-    total = None
-    for v in mine:
-        l = render_loss(v)
-        total = l if total is None else total + l
+
+    def losses():
+        tot = None
+        for v in mine:   # the forwards of the rank's views are enqueued back to back (none waits once its camera is known)
+            l = render_loss(v)
+            tot = l if tot is None else tot + l
+        return tot
+
+    total = _checked(losses)
     n_views = len(views)
     if total is not None:
         # local contribution to the global mean; summed (not averaged) across ranks below
@@ -659,10 +711,15 @@ def field_view_parallel_step(compute_splats: Callable[[], dict], views: Sequence
     for k in keys:
         splats[k] = outputs[k].detach().requires_grad_(True)
     mine = shard_views(views, rank, world)
-    total = None
-    for v in mine:
-        l = render_loss(splats, v)
-        total = l if total is None else total + l
+
+    def losses():
+        tot = None
+        for v in mine:
+            l = render_loss(splats, v)
+            tot = l if tot is None else tot + l
+        return tot
+
+    total = _checked(losses)
     n_views = len(views)
     ref = outputs[keys[0]]
     if total is not None:

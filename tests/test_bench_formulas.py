@@ -124,3 +124,16 @@ def test_source_hash_ignores_comments_and_layout(tmp_path, monkeypatch):
         (src / "k.hip").write_text(text)
         hashes.append(build.source_hash())
     assert hashes[0] == hashes[1] != hashes[2]
+
+
+def test_rank_count_mismatch_is_a_hard_error():
+    """--gpus N must be the number of ranks that run: a launcher that started another number is refused before anything is timed
+    (checked ahead of the device probe, so this runs without a GPU)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gpus, ws in (("2", "1"), ("1", "2"), ("4", "2")):
+        env = dict(os.environ, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", gpus], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode != 0 and f"--gpus {gpus} but WORLD_SIZE={ws}" in r.stderr, (gpus, ws, r.stderr[-500:])

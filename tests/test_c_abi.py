@@ -33,13 +33,30 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.sr_version() == 3
+    from splatfields_amd import _lib
+    assert lib.sr_version() == _lib.SR_VERSION == 4
     g1, g2 = lib.sr_geom_bytes(1000, 64, 64), lib.sr_geom_bytes(2000, 64, 64)
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert lib.sr_binning_bytes(1000, 64, 64) >= 1000 * 28  # ent 8 + merge ping-pong 2 x 8 + sorted ids 4 bytes per instance
     assert lib.sr_image_bytes(800, 800) >= 800 * 800 * 8
     assert lib.sr_backward_scratch_bytes(1000) >= 1000 * 48
     assert lib.sr_profile_stage_name(5) == b"render_backward"
+
+
+def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
+    """struct layouts / workspace contracts belong to an ABI version; the binding checks it at load."""
+    from splatfields_amd import _lib
+    monkeypatch.setattr(_lib, "SR_VERSION", _lib.SR_VERSION + 1)
+    with pytest.raises(RuntimeError, match="version 4 of the splatraster ABI"):
+        _lib.bind(_lib.LIB_PATH)
+
+
+def test_host_sync_counters_start_at_zero_and_reset(lib):
+    out = (C.c_longlong * 4)()
+    assert lib.sr_debug_counters(out, 1) == 0
+    assert lib.sr_debug_counters(out, 0) == 0 and list(out) == [0, 0, 0, 0]
+    assert lib.sr_debug_counters(None, 0) != 0
+    assert lib.sr_ticket_wait(None, None, None) != 0 and b"null ticket" in lib.sr_last_error()
 
 
 def test_struct_layouts_match_header():
@@ -103,6 +120,7 @@ def test_header_constants_match_the_binding():
     text = open(os.path.join(ROOT, "include", "splatraster.h")).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+(SR_[A-Z_]+)\s+(\d+)\b", text, re.M)}
     assert defs["SR_NEED_CAPACITY"] == _lib.SR_NEED_CAPACITY
+    assert defs["SR_VERSION"] == _lib.SR_VERSION
     assert (defs["SR_RAW_SCALES"], defs["SR_RAW_OPACITY"], defs["SR_RAW_ROTATIONS"], defs["SR_FORWARD_ONLY"]) == \
         (_lib.SR_RAW_SCALES, _lib.SR_RAW_OPACITY, _lib.SR_RAW_ROTATIONS, _lib.SR_FORWARD_ONLY)
     assert defs["SR_PROFILE_STAGES"] == _lib.PROFILE_STAGES

@@ -120,6 +120,13 @@ def test_reference_checkpoint_round_trip(hip_device, tmp_path):
         for frame in (0, 7, 11):
             assert torch.equal(a(xyz, feat, frame_id=frame), b(xyz, feat, frame_id=torch.tensor(frame, device=hip_device)))
         assert not torch.equal(a(xyz, feat, frame_id=0), a(xyz, feat, frame_id=1))
+        # negative indices wrap as the reference's `mat[frame_id]` does -- host ints and device tensors alike
+        assert torch.equal(a(xyz, feat, frame_id=-1), a(xyz, feat, frame_id=11))
+        assert torch.equal(a(xyz, feat, frame_id=torch.tensor(-1, device=hip_device)), a(xyz, feat, frame_id=11))
+        assert torch.equal(a(xyz, feat, frame_id=torch.tensor(-12, device=hip_device)), a(xyz, feat, frame_id=0))
+        # a device-side index outside [-capacity, capacity) cannot raise from a kernel: the weights are poisoned instead
+        assert torch.isnan(a(xyz, feat, frame_id=torch.tensor(-13, device=hip_device))).all()
+        assert torch.isnan(a(xyz, feat, frame_id=torch.tensor(12, device=hip_device))).all()
 
 
 def test_normalize_activation_matches_torch():

@@ -1,0 +1,201 @@
+"""The forward that does not block the host (include/splatraster.h: sr_forward_async; SURVEY.md section 8b "... or is avoided with
+a capacity-bounded workspace"; [EXT] reads num_rendered back in the middle of every forward).
+
+A camera that was rendered before (same splat count) is launched without waiting for its instance count; the ticket is redeemed
+at the backward.  Checked here: the library's own counters prove that no forward waited, V forwards go out back to back, results
+are bit-identical to the waiting path, a capacity guess that does not hold is detected before any gradient leaves and the retry
+succeeds, and dropped forwards hand their tickets back."""
+import math
+
+import pytest
+import torch
+
+from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
+
+pytestmark = pytest.mark.gpu
+N, W, H = 6000, 176, 128
+NAMES = ["means3D", "scales", "rotations", "opacities", "shs"]
+
+
+def _settings(cam, bg, deg=3):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2),
+                                         bg, 1.0, cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center, False, False)
+
+
+def _leaves(sp):
+    return {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+
+
+def _forward(p, cam, bg):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    m2 = torch.zeros_like(p["means3D"], requires_grad=True)
+    out = GaussianRasterizer(_settings(cam, bg)).forward_ex(means3D=p["means3D"], means2D=m2, opacities=p["opacities"], shs=p["shs"],
+                                                            scales=p["scales"], rotations=p["rotations"])
+    return out, m2
+
+
+def _step(sp, cams, bg, grads):
+    """the reference's iteration (train.py:158-252): every view of the step rendered, losses added, ONE backward"""
+    p = _leaves(sp)
+    gi, gd, ga = grads
+    loss, keep = 0.0, []
+    for cam in cams:
+        (c, r, d, a), m2 = _forward(p, cam, bg)
+        loss = loss + (c * gi).sum() + (d * gd).sum() + (a * ga).sum()
+        keep.append((c.detach(), d.detach(), a.detach(), r, m2))
+    loss.backward()
+    torch.cuda.synchronize()
+    return {k: v.grad.clone() for k, v in p.items()}, keep
+
+
+@pytest.fixture()
+def scene(hip_device):
+    from splatfields_amd import rasterizer as rz
+    prev = rz.set_async_forward(True)
+    sp = make_splats(N, seed=21, device=hip_device, mean_scale=0.02)
+    cams = [make_camera(v, W, H, device=hip_device) for v in range(4)]   # persistent camera tensors, as a training loop has them
+    bg = torch.ones(3, device=hip_device)
+    grads = make_upstream_grads(H, W, device=hip_device)
+    yield sp, cams, bg, grads
+    rz.set_async_forward(prev)
+
+
+def test_known_cameras_are_launched_without_a_host_wait_and_give_identical_results(scene):
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    rz.set_async_forward(False)
+    ref_g, ref_out = _step(sp, cams, bg, grads)                 # every forward waits (rounds 1-4); the cameras are known now
+    rz.set_async_forward(True)
+    rz.host_sync_counters(reset=True)
+    g, out = _step(sp, cams, bg, grads)
+    c = rz.host_sync_counters()
+    assert c["forward_host_waits"] == 0 and c["async_forwards"] == len(cams), c   # V forwards enqueued back to back, none waited
+    for k in NAMES:
+        assert torch.equal(g[k], ref_g[k]), k
+    for a, b in zip(out, ref_out):
+        for x, y in zip(a[:4], b[:4]):
+            assert torch.equal(x, y)
+        assert torch.equal(a[4].grad, b[4].grad)                  # means2D.grad of every view
+    assert rz.LAST_INSTANCES > 0
+
+
+def test_first_render_of_a_camera_waits_and_the_second_does_not(scene):
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    cam = make_camera(6, W, H, device=sp["means3D"].device)      # a camera nobody has rendered yet
+    rz.host_sync_counters(reset=True)
+    _step(sp, [cam], bg, grads)
+    assert rz.host_sync_counters()["forward_host_waits"] == 1 and rz.host_sync_counters()["async_forwards"] == 0
+    _step(sp, [cam], bg, grads)
+    c = rz.host_sync_counters()
+    assert c["forward_host_waits"] == 1 and c["async_forwards"] == 1, c
+    # a new splat count (densification) is a new situation: waits again
+    sp2 = {k: v[:N - 512].contiguous() for k, v in sp.items()}
+    _step(sp2, [cam], bg, grads)
+    assert rz.host_sync_counters()["forward_host_waits"] == 2
+    # rendering under no_grad never goes asynchronous (nothing would redeem the ticket before the image is used)
+    with torch.no_grad():
+        _forward({k: v for k, v in sp.items()}, cam, bg)
+    assert rz.host_sync_counters()["forward_host_waits"] == 3
+
+
+def test_a_capacity_guess_that_does_not_hold_raises_before_any_gradient_and_the_retry_succeeds(scene):
+    """same camera, same splat count, but the splats have grown 3 x since its last render: far more instances than promised"""
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    cam = cams[1]
+    _step(sp, [cam], bg, grads)                                   # the camera's record: ~ N * 3 instances
+    big = dict(sp, scales=sp["scales"] * 3.0)
+    rz.set_async_forward(False)
+    ref_g, ref_out = _step(big, [cam], bg, grads)
+    rz.set_async_forward(True)
+    # (the waiting render above refreshed the record: make it stale again)
+    pack = rz._ViewPack.get(_settings(cam, bg), sp["means3D"].device, 16)
+    _step(sp, [cam], bg, grads)
+    inst_small = pack.seen[N][0]
+    key = (sp["means3D"].device.index, N, H, W)
+    rz._CAPACITY[key] = rz._round_capacity(inst_small)            # as if only the small cloud had ever been seen
+    p = _leaves(big)
+    (c, r, d, a), m2 = _forward(p, cam, bg)
+    loss = (c * grads[0]).sum() + (d * grads[1]).sum() + (a * grads[2]).sum()
+    with pytest.raises(rz.RasterizerOverflow, match="re-run the step"):
+        loss.backward()
+    assert all(v.grad is None for v in p.values())                # nothing was applied
+    assert rz._CAPACITY[key] >= pack.seen[N][0] > inst_small      # the estimates are corrected ...
+    g, out = _step(big, [cam], bg, grads)                         # ... so the retry goes through (asynchronously again)
+    for k in NAMES:
+        assert torch.equal(g[k], ref_g[k]), k
+    assert torch.equal(out[0][0], ref_out[0][0])
+
+
+def test_a_list_longer_than_the_launched_sort_classes_is_detected(hip_device):
+    """capacity fine, but one tile list is longer than the classes the hint selected: the blend must not touch the unsorted
+    list (its ids were never written) and the ticket reports it"""
+    from splatfields_amd import rasterizer as rz
+    prev = rz.set_async_forward(True)
+    try:
+        sp = make_splats(40000, seed=5, device=hip_device, mean_scale=0.2)       # 64 x 64 image: lists of thousands of entries
+        cam = make_camera(2, 64, 64, device=hip_device)
+        bg = torch.ones(3, device=hip_device)
+        grads = make_upstream_grads(64, 64, device=hip_device)
+        ref_g, ref_out = _step(sp, [cam], bg, grads)
+        pack = rz._ViewPack.get(_settings(cam, bg), hip_device, 16)
+        inst, longest = pack.seen[40000]
+        assert longest > 2048
+        pack.seen[40000] = (inst, 100)                                           # a stale promise: "lists of 100 entries"
+        p = _leaves(sp)
+        (c, r, d, a), m2 = _forward(p, cam, bg)
+        with pytest.raises(rz.RasterizerOverflow, match=f"a list of {longest}"):
+            ((c * grads[0]).sum()).backward()
+        assert pack.seen[40000] == (inst, longest)
+        g, out = _step(sp, [cam], bg, grads)
+        for k in NAMES:
+            assert torch.equal(g[k], ref_g[k]), k
+    finally:
+        rz.set_async_forward(prev)
+
+
+def test_resolve_pending_and_the_step_functions_re_render_transparently(scene):
+    from splatfields_amd import rasterizer as rz
+    from splatfields_amd.view_parallel import sh_gather_step
+    sp, cams, bg, grads = scene
+    gi, gd, ga = grads
+    V = len(cams)
+
+    def run():
+        p = _leaves(sp)
+
+        def bwd(vi, c, d, a):
+            torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
+        sh_gather_step(p, cams, bg, 3, bwd, rank=0, world=1)
+        torch.cuda.synchronize()
+        return {k: v.grad.clone() for k, v in p.items()}
+
+    ref = run()
+    for cam in cams:                                              # stale promises for every camera of the step
+        pack = rz._ViewPack.get(_settings(cam, bg), sp["means3D"].device, 16)
+        pack.seen[N] = (pack.seen[N][0] // 8, pack.seen[N][1])
+    key = (sp["means3D"].device.index, N, H, W)
+    rz._CAPACITY[key] = rz._round_capacity(rz.LAST_INSTANCES // 8)
+    got = run()                                                   # no exception: redeemed before the backward, re-rendered
+    for k in NAMES:
+        assert torch.equal(got[k], ref[k]), k
+    # explicit form
+    p = _leaves(sp)
+    _forward(p, cams[0], bg)
+    rz.resolve_pending()                                          # nothing pending afterwards
+    assert not [r for r in (getattr(rz._TLS, "pending", None) or []) if r() is not None and r().ticket is not None]
+
+
+def test_dropped_forwards_hand_their_tickets_back(scene):
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    _step(sp, cams[:1], bg, grads)
+    before = rz.host_sync_counters()["tickets_created"]
+    p = _leaves(sp)
+    for _ in range(40):                                           # evaluation code that forgot no_grad: outputs dropped, no backward
+        out = _forward(p, cams[0], bg)
+        del out
+    torch.cuda.synchronize()
+    assert rz.host_sync_counters()["tickets_created"] - before <= 4

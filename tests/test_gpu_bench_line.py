@@ -82,3 +82,17 @@ def test_two_rank_line_carries_the_exchange_diagnostics(hip_device, mode):
     # gather: all-gather of 2 x 12 B/splat -> 12; shard: two all-to-alls of 12 B/splat -> 6 + 6; plain: 236 B/splat in one buffer
     want = {"gather": n * (12 + geo), "allreduce": n * (192 + geo), "shard": n * (6 + 6 + geo)}[mode]
     assert abs(ex["wire_bytes_per_gpu"] - want) <= 0.02 * want, (ex["wire_bytes_per_gpu"], want)
+
+
+def test_bench_launches_its_own_ranks_when_started_without_a_launcher(hip_device):
+    """`python bench.py --gpus 2` with no torch.distributed.run around it and no WORLD_SIZE in the environment must start two
+    ranks itself and report n_gpus == 2 (round 4's bench silently ran one rank and printed n_gpus: 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["exchange"]["rccl_ranks"] == 2 and d["config"]["views_per_step"] == 2
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1   # ONE line, from rank 0
+    # the timed steps render cameras that were rendered before: no forward waits on the host
+    assert d["host_sync"]["forward_host_waits"] == 0 and d["host_sync"]["async_forwards"] >= 4

@@ -85,7 +85,13 @@ def _reference_grads(dev, n=N, V=V):
     return {k: v.grad.detach().cpu() for k, v in p.items()}
 
 
-def _gather_grads(dev, rank, world, V=V, slices=None):
+def _regulariser(p):
+    """a loss term that reaches the leaves OUTSIDE the rasterizer (scale / opacity / SH regularisers of a training loss)"""
+    return 1e-3 * (p["scales"] ** 2).sum() + 2e-3 * p["opacities"].sum() + 1e-4 * (p["shs"][:, 1:] ** 2).sum() \
+        + 1e-3 * (p["means3D"] * p["rotations"][:, :3]).sum()
+
+
+def _gather_grads(dev, rank, world, V=V, slices=None, regularise=False):
     from splatfields_amd.view_parallel import sh_gather_step
     sp = make_splats(N, seed=7, device=dev)
     p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
@@ -93,6 +99,10 @@ def _gather_grads(dev, rank, world, V=V, slices=None):
     cams = [make_camera(v, W, H, device=dev) for v in range(V)]
 
     def bwd(vi, c, d, a):
+        if regularise:   # every view's loss carries the term / V, as `(loss / V).backward()` of a regularised loss does
+            loss = (c * gi).sum() + (d * gd).sum() + (a * ga).sum() + _regulariser(p)
+            (loss / V).backward()
+            return
         torch.autograd.backward((c, d, a), (gi / V, gd / V, ga / V))
 
     sh_gather_step(p, cams, torch.ones(3, device=dev), DEG, bwd, rank=rank, world=world, slices=slices)
@@ -110,12 +120,12 @@ def test_gather_step_single_rank_equals_plain_multiview(hip_device):
     _close(_gather_grads(hip_device, 0, 1), _reference_grads(hip_device))
 
 
-def _worker(rank, world, port, q, views=V, slices=None):
+def _worker(rank, world, port, q, views=V, slices=None, regularise=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")  # both ranks share the single GPU of the test box; gloo moves the tensors
     torch.cuda.set_device(dev)
-    g = _gather_grads(dev, rank, world, views, slices)
+    g = _gather_grads(dev, rank, world, views, slices, regularise)
     q.put((rank, {k: v.numpy().copy() for k, v in g.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -159,6 +169,49 @@ def test_sliced_gather_step_two_ranks_one_view_each(hip_device, slices):
     # both ranks hold bit-identical gradients (what replicated Adam needs)
     for k in NAMES:
         assert (outs[0][1][k] == outs[1][1][k]).all(), k
+
+
+def _reference_grads_regularised(dev, V):
+    """single process: mean over the views of (view loss + regulariser), one backward per view"""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    sp = make_splats(N, seed=7, device=dev)
+    p = {k: sp[k].clone().requires_grad_(True) for k in NAMES}
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    for v in range(V):
+        cam = make_camera(v, W, H, device=dev)
+        c, r, d, a = GaussianRasterizer(_rs(cam, dev)).forward_ex(means3D=p["means3D"], means2D=torch.zeros_like(p["means3D"]),
+                                                                  opacities=p["opacities"], shs=p["shs"], scales=p["scales"],
+                                                                  rotations=p["rotations"])
+        (((c * gi).sum() + (d * gd).sum() + (a * ga).sum() + _regulariser(p)) / V).backward()
+    return {k: v.grad.detach().cpu() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("slices", [1, 4])
+def test_gather_step_with_a_regulariser_outside_the_rasterizer(hip_device, slices):
+    """a loss term that reaches scales / opacities / SH / means outside the rasterizer.  The sliced exchange
+    (gradients written into the hook's buffers, autograd gets None from the rasterizer) must not lose it: both forms equal the
+    single-process regularised step, on both ranks, bit-identical across the ranks."""
+    ref = _reference_grads_regularised(hip_device, 2)
+    plain = _reference_grads(hip_device, V=2)
+    assert not torch.allclose(ref["scales"], plain["scales"], atol=1e-6 * plain["scales"].abs().max().item())   # the term matters
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 2, slices, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, g in outs:
+        _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
+    for k in NAMES:
+        assert (outs[0][1][k] == outs[1][1][k]).all(), k
+
+
+def test_gather_step_single_rank_with_a_regulariser(hip_device):
+    _close(_gather_grads(hip_device, 0, 1, regularise=True), _reference_grads_regularised(hip_device, V))
 
 
 def test_sliced_backward_equals_the_unsliced_one_bit_for_bit(hip_device):

@@ -29,6 +29,9 @@ __global__ void __launch_bounds__(256) k(float* out, int n) {
             if (KIND == 8) { asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (KIND == 9) { asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (KIND == 10) { asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"((int)((threadIdx.x ^ 5) & 63) << 2)); }
+            if (KIND == 16) { asm volatile("v_cmp_lt_u64 %4, %0, %1\n v_cmp_lt_u64 %4, %1, %2\n v_cmp_lt_u64 %4, %2, %3\n v_cmp_lt_u64 %4, %3, %0\n v_cmp_lt_u64 %4, %0, %2\n v_cmp_lt_u64 %4, %1, %3\n v_cmp_lt_u64 %4, %2, %0\n v_cmp_lt_u64 %4, %3, %1" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6), "=s"(m)); }
+            if (KIND == 17) { asm volatile("v_cmp_lt_u32 %8, %0, %1\n v_cmp_lt_u32 %8, %1, %2\n v_cmp_lt_u32 %8, %2, %3\n v_cmp_lt_u32 %8, %3, %4\n v_cmp_lt_u32 %8, %4, %5\n v_cmp_lt_u32 %8, %5, %6\n v_cmp_lt_u32 %8, %6, %7\n v_cmp_lt_u32 %8, %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=s"(m)); }
+            if (KIND == 18) { asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (KIND == 11) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc"); }
         }
     }
@@ -52,6 +55,7 @@ int main() {
     run<0>(d, "v_fma_f32"); run<1>(d, "v_mul_f32"); run<2>(d, "v_exp_f32"); run<3>(d, "v_cmp_lt_f32 -> sgpr"); run<11>(d, "v_cmp_lt_f32 -> vcc");
     run<4>(d, "v_cndmask_b32 (sgpr)"); run<5>(d, "v_add_f32_dpp"); run<6>(d, "v_permlane32_swap"); run<7>(d, "v_pk_fma_f32"); run<8>(d, "v_rcp_f32");
     run<9>(d, "v_mov_b32"); run<10>(d, "ds_bpermute_b32");
+    run<16>(d, "v_cmp_lt_u64 -> sgpr"); run<17>(d, "v_cmp_lt_u32 -> sgpr"); run<18>(d, "v_mov_b32_dpp");
     run<12>(d, "v_fma exec=lanes 0-31"); run<13>(d, "v_fma exec=lanes 0-15"); run<14>(d, "v_fma exec=rows 0,2"); run<15>(d, "v_fma exec=lanes 0-7");
     return 0;
 }
