@@ -488,8 +488,11 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
     const uint32_t* qms = b.qmask + start;
 #ifndef SR_BWD_EARLY_PIX
-#define SR_BWD_EARLY_PIX 1   // 1: the per-pixel inputs are requested BETWEEN the splat-index load and the record gather that depends
-#endif                       //    on it (one memory round trip less in every tile's preamble); 0: behind the gather (rounds 2-4)
+#define SR_BWD_EARLY_PIX 0   // 1: the per-pixel inputs are requested BETWEEN the splat-index load and the record gather that depends
+#endif                       //    on it (one memory round trip less in a tile's preamble on paper); 0: behind the gather.
+                             //    Measured in round 5 (same box, alternated): 0.1977 vs 0.1933 ms, SLOWER -- the record gather is
+                             //    what the first chunk waits for, and six more requests per lane in front of it delay it
+
     const uint32_t id_first = ids[max(hi - 1 - tid, 0)];
     uint32_t id_next = ids[max(hi - kChunk - 1 - tid, 0)];   // its splat index: loaded another chunk earlier
 #if !SR_BWD_EARLY_PIX

@@ -162,6 +162,7 @@ class _Pending:
         if len(lst) > 64:
             lst[:] = [r for r in lst if r() is not None]
         lst.append(weakref.ref(self))
+        self._list = lst   # the launching thread's list: the ticket is usually redeemed on autograd's device thread
 
     def resolve(self) -> int:
         """Redeems the ticket (waits for stage 1 of that forward if it is still running); returns the instance count or raises
@@ -170,9 +171,8 @@ class _Pending:
             ticket, self.ticket = self.ticket, None
             inst, longest = C.c_longlong(0), C.c_longlong(0)
             rc = self.lib.sr_ticket_wait(ticket, C.byref(inst), C.byref(longest))
-            lst = getattr(_TLS, "pending", None)
-            if lst is not None:
-                lst[:] = [r for r in lst if r() is not None and r() is not self]
+            lst = self._list
+            lst[:] = [r for r in lst if r() is not None and r() is not self]
             _lib.check(rc)
             self.instances = int(inst.value)
             instances, longest = int(inst.value), int(longest.value)
@@ -306,7 +306,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings: GaussianRasterizationSettings, color_grad_sink=None, raw_params: int = 0, sh_rest=None,
-                slice_hook=None):
+                slice_hook=None, grad_mode: bool = True):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("splatfields_amd rasterizer has no CPU path: tensors must be on a HIP ('cuda') device")
@@ -354,7 +354,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.color_grad_sink = color_grad_sink
         ctx.slice_hook = slice_hook
         # nothing to differentiate (rendering / evaluation under no_grad): the forward skips what only the backward reads
-        if not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]):
+        # (`needs_input_grad` reflects the inputs' requires_grad flags even under torch.no_grad(): the caller's grad mode --
+        # autograd switches it off inside this function -- arrives as an argument)
+        if not grad_mode or (not any(ctx.needs_input_grad[:8]) and not (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11])):
             raw_params = int(raw_params) | _lib.SR_FORWARD_ONLY
         ctx.raw_params = int(raw_params)
         ctx.sh_coeffs = sh_coeffs
@@ -435,7 +437,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         n = ctx.n
         if n == 0:
-            return (None,) * 13
+            return (None,) * 14
         lib = _lib.load()
         if ctx.pending is not None:
             # the forward did not wait for its instance count: redeem its ticket now (stage 1 of that forward is long over;
@@ -488,7 +490,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                       _ptr(image), _ptr(radii), _ptr(scratch), C.byref(grads), lo, hi - lo, stream))
                     hook.on_slice(j, lo, hi)
         if hook is not None:
-            return (None, d_means2D) + (None,) * 11
+            return (None, d_means2D) + (None,) * 12
         # order of the forward inputs: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D, settings
         if sink is not None:
             sink.append(d_col)  # clamp-masked dL/dcolour of this view; dL/dsh is rebuilt from all views by the caller
@@ -498,7 +500,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = [g_ if (g_ is None or dt is None or g_.dtype == dt) else g_.to(dt) for g_, dt in zip(grads, ctx.in_dtypes)]
         if d_rest is not None and ctx.rest_dtype is not None and d_rest.dtype != ctx.rest_dtype:
             d_rest = d_rest.to(ctx.rest_dtype)
-        return (*grads, None, None, None, d_rest, None)
+        return (*grads, None, None, None, d_rest, None, None)
 
 
 def slice_ranges(n: int, slices: int) -> list:
@@ -515,7 +517,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     the reference's second rasterization with white colours on a black background
     (gaussian_renderer/__init__.py:104-115)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params, sh_rest, slice_hook)
+                                     cov3Ds_precomp, raster_settings, color_grad_sink, raw_params, sh_rest, slice_hook,
+                                     torch.is_grad_enabled())
 
 
 class GaussianRasterizer(nn.Module):

@@ -101,14 +101,16 @@ def test_first_render_of_a_camera_waits_and_the_second_does_not(scene):
 
 
 def test_a_capacity_guess_that_does_not_hold_raises_before_any_gradient_and_the_retry_succeeds(scene):
-    """same camera, same splat count, but the splats have grown 3 x since its last render: far more instances than promised"""
+    """same camera, same splat count, but the splats have grown 12 x since its last render: far more instances than promised
+    (the smallest capacity the facade ever uses is 65536 instances: the grown cloud must exceed it)"""
     from splatfields_amd import rasterizer as rz
     sp, cams, bg, grads = scene
     cam = cams[1]
     _step(sp, [cam], bg, grads)                                   # the camera's record: ~ N * 3 instances
-    big = dict(sp, scales=sp["scales"] * 3.0)
+    big = dict(sp, scales=sp["scales"] * 12.0)
     rz.set_async_forward(False)
     ref_g, ref_out = _step(big, [cam], bg, grads)
+    assert rz.LAST_INSTANCES > 2 * 65536
     rz.set_async_forward(True)
     # (the waiting render above refreshed the record: make it stale again)
     pack = rz._ViewPack.get(_settings(cam, bg), sp["means3D"].device, 16)
@@ -160,6 +162,7 @@ def test_resolve_pending_and_the_step_functions_re_render_transparently(scene):
     from splatfields_amd import rasterizer as rz
     from splatfields_amd.view_parallel import sh_gather_step
     sp, cams, bg, grads = scene
+    sp = dict(sp, scales=sp["scales"] * 12.0)                     # ~50 tiles per splat
     gi, gd, ga = grads
     V = len(cams)
 
@@ -173,12 +176,15 @@ def test_resolve_pending_and_the_step_functions_re_render_transparently(scene):
         return {k: v.grad.clone() for k, v in p.items()}
 
     ref = run()
+    assert rz.LAST_INSTANCES > 2 * 65536                          # (65536 = the smallest capacity the facade uses)
     for cam in cams:                                              # stale promises for every camera of the step
         pack = rz._ViewPack.get(_settings(cam, bg), sp["means3D"].device, 16)
         pack.seen[N] = (pack.seen[N][0] // 8, pack.seen[N][1])
     key = (sp["means3D"].device.index, N, H, W)
     rz._CAPACITY[key] = rz._round_capacity(rz.LAST_INSTANCES // 8)
+    rz.host_sync_counters(reset=True)
     got = run()                                                   # no exception: redeemed before the backward, re-rendered
+    assert rz.host_sync_counters()["async_forwards"] > len(cams)  # at least one forward was launched twice
     for k in NAMES:
         assert torch.equal(got[k], ref[k]), k
     # explicit form
