@@ -173,15 +173,7 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
     torch.cuda.synchronize()
     ms_per_step = (time.perf_counter() - t0) / steps * 1e3
     ms_median = median([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)])
-    lib.sr_profile_enable(1)
-    for i in range(steps):
-        step(warmup + i, record=(i == steps - 1))
-    torch.cuda.synchronize()
-    ms = (C.c_double * _lib.PROFILE_STAGES)()
-    cnt = (C.c_longlong * _lib.PROFILE_STAGES)()
-    lib.sr_profile_collect(ms, cnt)
-    lib.sr_profile_enable(0)
-    stage_ms = {lib.sr_profile_stage_name(i).decode(): (ms[i] / max(cnt[i], 1)) for i in range(_lib.PROFILE_STAGES)}
+    stage_ms = staged_pass(lib, steps, lambda i: step(warmup + i, record=(i == steps - 1)))
     R = float(rz.LAST_INSTANCES)
     c_in = 12 * 16 if use_sh else 12
     b_alg = pipeline_bytes(n, vis[0], R, height * width, c_in)
@@ -195,6 +187,33 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
             "sort_keys_per_s": R / (stage_ms["sort_tiles"] * 1e-3) if stage_ms["sort_tiles"] > 0 else None,
             "roofline_pipeline_frac": b_alg / (ms_per_step * 1e-3) / HBM_PEAK,
             "roofline_pipeline_frac_from_median": b_alg / (ms_median * 1e-3) / HBM_PEAK if ms_median > 0 else None}
+
+
+def staged_pass(lib, n_steps: int, step_fn) -> dict:
+    """Per-stage durations (HIP events on the launch stream inside the library, sr_profile_enable): `n_steps` steps, collected
+    step by step; per stage the AVERAGE over the steps, leaving out steps that took more than three times the stage's median --
+    one slow launch (a clock or allocator hiccup on the box: round 5's first run showed one 3 ms forward among 20 in a side
+    workload, which made a 0.08 ms stage read 0.24) does not become the figure."""
+    from splatfields_amd import _lib
+    lib.sr_profile_enable(1)
+    per = [[] for _ in range(_lib.PROFILE_STAGES)]
+    for i in range(n_steps):
+        step_fn(i)
+        ms = (C.c_double * _lib.PROFILE_STAGES)()
+        cnt = (C.c_longlong * _lib.PROFILE_STAGES)()
+        lib.sr_profile_collect(ms, cnt)
+        for k in range(_lib.PROFILE_STAGES):
+            if cnt[k] > 0:
+                per[k].append(ms[k])   # the stage's launches of this step together (e.g. the sort's two classes)
+    torch.cuda.synchronize()
+    lib.sr_profile_enable(0)
+    def robust_mean(xs):
+        if not xs:
+            return 0.0
+        m = median(xs)
+        keep = [x for x in xs if x <= 3.0 * m] or xs
+        return sum(keep) / len(keep)
+    return {lib.sr_profile_stage_name(k).decode(): robust_mean(per[k]) for k in range(_lib.PROFILE_STAGES)}
 
 
 def blend_work_counters(n, width, height, mean_scale):
@@ -541,15 +560,7 @@ def main():
 
     progress(f"timed {args.steps} steps: wall-clock mean {ms_per_step:.4f} ms/step, median {ms_median:.4f}")
     # ---- per-stage durations with HIP events on the launch stream (same steps, same inputs) ----
-    lib.sr_profile_enable(1)
-    for i in range(args.steps):
-        one_step(args.warmup + i, record=True)
-    torch.cuda.synchronize()
-    ms = (C.c_double * _lib.PROFILE_STAGES)()
-    cnt = (C.c_longlong * _lib.PROFILE_STAGES)()
-    lib.sr_profile_collect(ms, cnt)
-    lib.sr_profile_enable(0)
-    stage_ms = {lib.sr_profile_stage_name(i).decode(): (ms[i] / max(cnt[i], 1)) for i in range(_lib.PROFILE_STAGES)}
+    stage_ms = staged_pass(lib, args.steps, lambda i: one_step(args.warmup + i, record=True))
     R = stats["R"] / max(stats["n"], 1)
     vis = stats["vis"] / max(stats["n"], 1)
     b_alg = pipeline_bytes(N, vis, R, H * W, c_in)

@@ -174,6 +174,29 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #endif
         s_qm[buf][slot] = (uint16_t)qm;
     };
+#ifndef SR_FWD_REGSTAGE
+#define SR_FWD_REGSTAGE 0   // 1: the NEXT batch's records travel into registers while the current batch is blended and are written
+#endif                      //    to the (single) staging area behind the batch's barrier: no memory round trip between two batches.
+                            //    0: LDS-direct copies requested behind the barrier (the gather's latency is exposed once per
+                            //    batch and covered by the CU's other workgroups).  Measured in round 5, same box, alternated
+                            //    three times: 0.0882 vs 0.0878 ms at the headline, 0.0638 vs 0.0631 / 0.0758 vs 0.0751 in the
+                            //    dense regimes -- the other workgroups DO cover it; the register form (64 registers, still eight
+                            //    wavefronts per SIMD) buys nothing and stays switched off
+    // the same from registers: the staged form of an entry -- (E0, F0, tau, depth) (p, p s, q, -log2 o) (r, g, b, depth) and its
+    // quad-reach mask -- written once
+    auto publish_regs = [&](int buf, uint32_t i, const float4 r0, const float4 r1, const float4 r2) {
+        uint32_t qm = 0u;
+        float4 s0 = r0, s1 = r1;
+        if (i < end) {
+            qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
+            b.qmask[i] = qm;
+            float E0, F0, ps;
+            exponent_terms(r0.x, r0.y, r1, tx0f, ty0f, E0, F0, ps);
+            s0.x = E0; s0.y = F0; s1.y = ps;
+        }
+        s_r0[buf][slot] = s0; s_r1[buf][slot] = s1; s_r2[buf][slot] = r2;
+        s_qm[buf][slot] = (uint16_t)qm;
+    };
     const uint32_t lastpos = end - 1u;
     const uint32_t i0 = start + (uint32_t)slot;   // this thread's entry of batch 0
     // Splat indices are plain loads with the index clamped into the list (unconditional: no branch).  id_nxt = index of this
@@ -202,6 +225,15 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #if SR_FWD_BUFS == 2
         // the other copy is free (every wavefront has passed the barrier behind its batch): start filling it
         if (more && stages(k + 1u)) request(nbuf, id_nxt);
+#endif
+#if SR_FWD_REGSTAGE && SR_FWD_BUFS == 1
+        // the next batch's records: requested now, used behind this batch's barrier (twelve registers; ordinary loads, so the
+        // compiler's own wait in front of their first use is exact)
+        float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
+        if (more && stages(k + 1u)) {
+            const float4* rec = g.rec + 4 * (size_t)id_nxt;
+            nx0 = rec[0]; nx1 = rec[1]; nx2 = rec[2];
+        }
 #endif
         const int cnt = (int)min((uint32_t)kB, end - base);
 #if SR_FWD_QUADS
@@ -346,13 +378,22 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #if SR_FWD_BUFS == 1
         lds_barrier();   // everybody is done with the batch: the one copy may be overwritten
         if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped
+#if !SR_FWD_REGSTAGE
         if (stages(k + 1u)) request(0, id_nxt);
 #endif
+#endif
+#if SR_FWD_REGSTAGE && SR_FWD_BUFS == 1
+        if (stages(k + 1u)) {
+            id_nxt = b.sorted_id[min(base + (1u + kStep) * kB + (uint32_t)slot, lastpos)];
+            publish_regs(0, base + kB + (uint32_t)slot, nx0, nx1, nx2);
+        }
+#else
         if (stages(k + 1u)) {
             lds_copy_wait();
             id_nxt = b.sorted_id[min(base + (1u + kStep) * kB + (uint32_t)slot, lastpos)];
             publish_mask(nbuf, base + kB + (uint32_t)slot);
         }
+#endif
         lds_barrier();
 #if SR_FWD_BUFS == 2
         if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped

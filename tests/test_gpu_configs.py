@@ -10,14 +10,24 @@ import torch
 from oracle import c_oracle
 from oracle import torch_oracle as O
 from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-from tests.helpers import grad_error, run_hip
+from tests.helpers import grad_error, record_observed, run_hip
 
 pytestmark = pytest.mark.gpu
 
 
-def compare_with_c_oracle(sp, st, grads, dev, use_sh, grad_tol=2e-3):
+def compare_with_c_oracle(sp, st, grads, dev, use_sh, grad_tol=2e-3, tag="config"):
     out, g = run_hip(sp, st, grads, dev, use_sh=use_sh)
     ref, cg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=16)
+    from oracle import parity as P
+    fig = P.compare(out, g, ref, cg)
+    record_observed(tag, {"image_share_above_1e-4": fig["image_share_above_1e-4"],
+                          "image_max_abs": max(v["max_abs"] for v in fig["images"].values()),
+                          "image_median_rel": max(v["median_rel"] for v in fig["images"].values()),
+                          "grad_max": fig["gradient_max_rel_to_tensor_max"],
+                          "grad_share_above_1e-3": max(v["share_above_1e-3"] for v in fig["gradients"].values()),
+                          "grad_share_above_tol": max(float(((g[k].double() - cg[k].double()).abs() > grad_tol * cg[k].double().abs().max()).double().mean())
+                                                      for k in cg),
+                          "grad_l2_rel": max(float((g[k].double() - cg[k].double()).norm() / cg[k].double().norm()) for k in cg)})
     # ceil(3 sqrt(lambda)) of two fp32 implementations may differ by one where the argument is within an ulp of an integer
     dr = (out["radii"].long() - ref["radii"].long()).abs()
     assert int((dr > 0).sum()) <= max(2, int(1e-5 * dr.numel())) and int(dr.max()) <= 1
@@ -45,7 +55,7 @@ def test_config1_lego_like_300k_six_views(hip_device):
     for view in range(6):
         cam = make_camera(view, 800, 800)
         st = O.settings_from_camera(cam, torch.ones(3), 3)
-        compare_with_c_oracle(sp, st, (gi, gd, ga), hip_device, use_sh=True)
+        compare_with_c_oracle(sp, st, (gi, gd, ga), hip_device, use_sh=True, tag=f"config1 view {view}")
 
 
 def test_config2_dtu_like_depth_regularised_three_views(hip_device):
@@ -55,7 +65,7 @@ def test_config2_dtu_like_depth_regularised_three_views(hip_device):
     for view in (0, 3, 5):
         cam = make_camera(view, 800, 600, elevation_deg=20.0)
         st = O.settings_from_camera(cam, torch.zeros(3), 3)
-        compare_with_c_oracle(sp, st, (gi, 50.0 * gd, 20.0 * ga), hip_device, use_sh=True)
+        compare_with_c_oracle(sp, st, (gi, 50.0 * gd, 20.0 * ga), hip_device, use_sh=True, tag=f"config2 view {view}")
 
 
 def test_config4_dynamic_sequence_precomputed_colours(hip_device):
@@ -73,7 +83,7 @@ def test_config4_dynamic_sequence_precomputed_colours(hip_device):
         for view in ((frame * 3) % 8, (frame * 3 + 1) % 8):
             cam = make_camera(view, 800, 800)
             st = O.settings_from_camera(cam, torch.ones(3), 0)
-            compare_with_c_oracle(sp, st, (gi, gd, ga), hip_device, use_sh=False)
+            compare_with_c_oracle(sp, st, (gi, gd, ga), hip_device, use_sh=False, tag=f"config4 frame {frame} view {view}")
 
 
 def test_two_views_then_one_backward_accumulates(hip_device):

@@ -4,9 +4,14 @@ invariance, and a 6 M-splat run."""
 import pytest
 import torch
 
-from tests.helpers import assert_grads_flip_aware, make_scene, run_hip
+from tests.helpers import assert_grads_flip_aware, make_scene, record_observed, run_hip
 
 pytestmark = pytest.mark.gpu
+
+# Share of pixels that may exceed 1e-4 relative error (two fp32 evaluations of alpha >= 1/255 / T >= 1e-4 flip on a few pixels):
+# observed on MI355X at the headline size 2e-5 .. 9e-5 per image (gpurun_out/parity_observed.jsonl, bench.py's `parity` block);
+# the bound is ~10 x that (rounds 1-4 allowed 5e-3).
+IMAGE_FLIP_SHARE = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +63,7 @@ def test_window_against_c_oracle(hip_device, scene):
         a, b = o1[k][sl].double(), ref[k][sl].double()
         rel = ((a - b).abs() / b.abs().clamp_min(1e-3))
         assert rel.median().item() < 1e-5
-        assert (rel > 1e-4).float().mean().item() < 5e-3, k  # both fp32: a few pixels flip a threshold decision
+        assert (rel > 1e-4).float().mean().item() < IMAGE_FLIP_SHARE, k  # both fp32: a few pixels flip a threshold decision
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
     assert torch.equal(o1["radii"], ref["radii"])
 
@@ -81,18 +86,29 @@ def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, s
     ref, rg, num_rendered = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2],
                                                threads=threads)
     assert torch.equal(out["radii"], ref["radii"])
+    from oracle import parity as P
+    fig = P.compare(out, g, ref, rg)
+    record_observed("headline sh view 1", {"image_share_above_1e-4": fig["image_share_above_1e-4"],
+                                           "image_max_abs": max(v["max_abs"] for v in fig["images"].values()),
+                                           "image_p999_rel": fig["image_max_rel_on_99.9pct_of_pixels"],
+                                           "grad_max": fig["gradient_max_rel_to_tensor_max"],
+                                           "grad_share_above_1e-3": max(v["share_above_1e-3"] for v in fig["gradients"].values())})
     for k in ("color", "depth", "alpha"):
         a, b = out[k].double(), ref[k].double()
         rel = (a - b).abs() / b.abs().clamp_min(1e-3)
         assert rel.median().item() < 1e-5, k
-        assert (rel > 1e-4).float().mean().item() < 5e-3, k   # both sides fp32: a few pixels flip a threshold decision
+        assert (rel > 1e-4).float().mean().item() < IMAGE_FLIP_SHARE, k   # both sides fp32: a few pixels flip a threshold decision
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
     assert_grads_flip_aware(g, rg, "sh")
     # the same for the precomputed-colour path of the headline ("both colour paths")
     out2, g2 = run_hip(sp, st, grads, hip_device, use_sh=False)
     ref2, rg2, _ = c_oracle.rasterize(sp, st, use_sh=False, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=threads)
+    fig2 = P.compare(out2, g2, ref2, rg2)
+    record_observed("headline precomputed colours view 1", {"image_share_above_1e-4": fig2["image_share_above_1e-4"],
+                                                            "grad_max": fig2["gradient_max_rel_to_tensor_max"],
+                                                            "grad_share_above_1e-3": max(v["share_above_1e-3"] for v in fig2["gradients"].values())})
     rel = (out2["color"].double() - ref2["color"].double()).abs() / ref2["color"].double().abs().clamp_min(1e-3)
-    assert rel.median().item() < 1e-5 and (rel > 1e-4).float().mean().item() < 5e-3
+    assert rel.median().item() < 1e-5 and (rel > 1e-4).float().mean().item() < IMAGE_FLIP_SHARE
     assert_grads_flip_aware(g2, rg2, "precomputed colours")
 
 
