@@ -353,6 +353,37 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def collective_probe(n_splats: int, world: int, dev, iters: int = 5) -> dict:
+    """Bus bandwidth of the exchange's collectives on this node, each alone (median of `iters`, after two warm-up calls):
+    all-gather of one view's colour gradients per rank (12 B/splat in, world x 12 out) and the in-place sum all-reduce of the
+    44 B/splat of geometric gradients.  bus bandwidth = ring-model wire bytes per GPU / time (the figure RCCL's own tests quote)."""
+    import torch.distributed as dist
+    res = {}
+    col = torch.zeros(n_splats, 3, device=dev)
+    gathered = torch.empty(world, n_splats, 3, device=dev)
+    geo = torch.zeros(n_splats, 11, device=dev)
+    f = (world - 1) / world
+
+    def timed(fn, wire_bytes):
+        ts = []
+        for i in range(iters + 2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ts.append(a.elapsed_time(b))
+        ms = median(ts)
+        return {"ms": ms, "wire_bytes_per_gpu": wire_bytes, "bus_GBps": wire_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None}
+
+    res["all_gather_colour_gradients"] = timed(lambda: dist.all_gather_into_tensor(gathered.view(-1), col.view(-1)), f * gathered.numel() * 4)
+    res["all_reduce_geometric_gradients"] = timed(lambda: dist.all_reduce(geo), 2 * f * geo.numel() * 4)
+    return res
+
+
 def headline_parity(kept: dict, n, height, width, use_sh, sh_degree, mean_scale, dev) -> dict:
     """One fwd+bwd of the HIP path on the oracle's inputs (view `kept['view']` of the seeded workload) compared with the C oracle's
     outputs and gradients (oracle/parity.py)."""
@@ -627,6 +658,13 @@ def main():
             "note": "rank 0's medians over the timed steps; exchange_ms = first collective issued -> last one complete (events on the "
                     "launch stream), overlap_ms = local compute inside that window (the SH-gradient rebuild), wire bytes by the ring "
                     "model (all-reduce 2 (G-1)/G S, all-gather / all-to-all (G-1)/G S)"}
+    if world > 1:
+        # measured bus bandwidth of the two collectives the exchange is made of, alone on an idle GPU (outside the timed region):
+        # what the prediction below should be read against on THIS node
+        out["exchange"]["collective_probe"] = collective_probe(N, world, dev)
+        ex_ms = out["exchange"].get("exchange_ms")
+        if ex_ms:
+            out["exchange"]["window_bus_GBps"] = out["exchange"]["wire_bytes_per_gpu"] / (ex_ms * 1e-3) / 1e9
     if world > 1 or args.force_dp_path:
         # what this scheme should cost on an 8-GPU node by link arithmetic (view_parallel.predict_scaling), from this run's own
         # stage times: the first SCALE curve can be checked against it

@@ -161,10 +161,13 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
  * finished -- and returns the instance count and the longest list; the outputs are valid iff
  *     instances <= binning_capacity  and  longest_list <= max(2048, the class bound the hint selected).
  * When they are not, re-run the forward (sr_forward, or sr_forward_async with the reported figures).
+ * `longest_list_expected` (<= the hint, or -1): the figure without its headroom.  A sort class that is launched only for the
+ * headroom's sake (no list of its length is expected) gets a grid of a few workgroups instead of 512: it finds nothing and
+ * leaves, or sorts the one list that did grow into it.
  * sr_ticket_release = sr_ticket_wait without results (a forward whose outputs were dropped).  A ticket is redeemed once. */
 int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
-                     long long binning_capacity, long long longest_list_hint, void* image, float* out_color, float* out_depth,
-                     float* out_alpha, void** ticket_out, void* hip_stream);
+                     long long binning_capacity, long long longest_list_hint, long long longest_list_expected, void* image,
+                     float* out_color, float* out_depth, float* out_alpha, void** ticket_out, void* hip_stream);
 int sr_ticket_wait(void* ticket, long long* instances_out, long long* longest_list_out);
 /* the longest tile list of the calling thread's most recent sr_forward (-1 before the first): the hint of a later
  * sr_forward_async of the same view */

@@ -79,7 +79,8 @@ SYMBOLS = {
     "sr_forward": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p]),
     "sr_forward_async": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
-                                   C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+                                   C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                   C.c_void_p]),
     "sr_ticket_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "sr_ticket_release": (C.c_int, [C.c_void_p]),
     "sr_last_longest_list": (C.c_longlong, []),

@@ -266,7 +266,7 @@ int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
 // hs == nullptr: nobody waits; `max_len` = the longest list the sort classes must cover (< 0: launch every class).
 int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, const sr::Binning& b,
                   const sr::Image& im, float* out_color, float* out_depth, float* out_alpha, HostSync* hs, long long max_len,
-                  hipStream_t st) {
+                  long long expected_len, hipStream_t st) {
     { StageTimer t_(2, st); sr::launch_emit(v, s.N, g, b, st); }
     SR_TRY(after_launch(view, st, "emit"));
     if (hs) {
@@ -277,7 +277,7 @@ int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
         // launching -- the caller re-runs it with a buffer that fits (SR_NEED_CAPACITY)
         if ((long long)hs->pinned[0] > (long long)b.capacity) return 0;
     }
-    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, max_len, st); }
+    { StageTimer t_(3, st); sr::launch_sort_tiles(v, g, b, max_len, expected_len, st); }
     SR_TRY(after_launch(view, st, "sort_tiles"));
     { StageTimer t_(4, st); sr::launch_render_forward(v, g, b, im, out_color, out_depth, out_alpha, st); }
     SR_TRY(after_launch(view, st, "render_forward"));
@@ -324,7 +324,7 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
     SR_TRY(get_host_sync(&hs));
     SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));   // k_scan_small stores the two counters into hs->pinned
     SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
-    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, -1, st));  // waits inside, GPU busy
+    SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, -1, -1, st));  // waits inside, GPU busy
     const long long total = (long long)hs->pinned[0];
     *instances_out = total;
     g_last_longest = (long long)hs->pinned[1];
@@ -345,12 +345,12 @@ int sr_forward_render(const SrView* view, const SrSplats* splats, void* geom, vo
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     sr::carve_binning(binning, instances, &b);
     sr::carve_image(image, v.H, v.W, &im);
-    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, -1, st);
+    return launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, -1, -1, st);
 }
 
 int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int* radii, void* binning,
-                     long long binning_capacity, long long longest_list_hint, void* image, float* out_color, float* out_depth,
-                     float* out_alpha, void** ticket_out, void* hip_stream) {
+                     long long binning_capacity, long long longest_list_hint, long long longest_list_expected, void* image,
+                     float* out_color, float* out_depth, float* out_alpha, void** ticket_out, void* hip_stream) {
     SR_TRY(validate(view, splats));
     g_call = CallContext{view, splats, "snapshot_fw.dump"};
     if (!geom || !binning || !image || !out_color || !out_depth || !ticket_out || (splats->count > 0 && !radii)) return fail("null buffer");
@@ -371,7 +371,8 @@ int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int
     t->pinned[0] = 0u; t->pinned[1] = 0u;
     int rc = launch_stage1(view, v, s, g, radii, t->pinned_dev, st);
     if (!rc) rc = check_hip(hipEventRecord(t->ev, st), "record");
-    if (!rc) rc = launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, covered, st);
+    if (!rc) rc = launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, covered,
+                                longest_list_expected >= 0 && longest_list_expected <= longest_list_hint ? longest_list_expected : -1, st);
     if (rc) {   // nothing of this call may still write the block when it is handed out again
         (void)hipStreamSynchronize(st);
         ticket_recycle(t);

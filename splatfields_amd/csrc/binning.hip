@@ -685,8 +685,12 @@ __global__ void __launch_bounds__(THREADS) k_sort_tiles_long(const Geom g, const
     }
 }
 
-// max_len: longest tile list if the host knows it (< 0: unknown, launch every class)
-void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st) {
+// max_len: longest tile list if the host knows it (< 0: unknown, launch every class).
+// expected_len (sr_forward_async; < 0: none): the longest list the caller really EXPECTS, max_len then being that figure with
+// headroom: a long-list class that is launched only because of the headroom -- no list of its length is expected -- gets a
+// grid of a few workgroups (they find Geom::total[4..6] = 0 slots and leave; should a list have grown into the class after
+// all, they sort it) instead of 512 x 1024 threads that start up to find nothing.
+void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, long long expected_len, hipStream_t st) {
     const int tiles = v.gx * v.gy;
     if (tiles <= 0) return;
     auto lds = [](int cap, int) { return (size_t)cap * 16; };   // the runs + the ping-pong buffer of the merge passes
@@ -697,11 +701,12 @@ void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long lon
     allow_dynamic_lds(reinterpret_cast<const void*>(&k_sort_tiles_long<8192, 1024>), 4, (int)lds(8192, 1024));
     // the long classes walk the head of tile_order (Geom::total[4..6] slots) with a grid of at most two workgroups per CU
     const int long_grid = tiles < 512 ? tiles : 512;
-    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(long_grid), dim3(1024), lds(4096, 1024), st, g, b, tiles);
+    auto grid_for = [&](long long lo) { return (expected_len >= 0 && expected_len <= lo) ? (long_grid < 8 ? long_grid : 8) : long_grid; };
+    hipLaunchKernelGGL((k_sort_tiles_merge<2048, 4096, 1024>), dim3(grid_for(2048)), dim3(1024), lds(4096, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 4096) return;
-    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(long_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_merge<4096, 8192, 1024>), dim3(grid_for(4096)), dim3(1024), lds(8192, 1024), st, g, b, tiles);
     if (max_len >= 0 && max_len <= 8192) return;
-    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(long_grid), dim3(1024), lds(8192, 1024), st, g, b, tiles);
+    hipLaunchKernelGGL((k_sort_tiles_long<8192, 1024>), dim3(grid_for(8192)), dim3(1024), lds(8192, 1024), st, g, b, tiles);
 }
 
 }  // namespace sr

@@ -30,7 +30,7 @@ inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixT
 void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st);
 void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, hipStream_t st);
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st);
-void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, hipStream_t st);
+void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, long long expected_len, hipStream_t st);
 // render.hip
 void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,
                            float* out_color, float* out_depth, float* out_alpha, hipStream_t st);

@@ -397,7 +397,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 covered = 2048 if hint <= 2048 else 4096 if hint <= 4096 else 8192 if hint <= 8192 else 1 << 62
                 ticket = C.c_void_p()
                 _lib.check(lib.sr_forward_async(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(radii), _ptr(binning),
-                                                capacity, hint, _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha),
+                                                capacity, hint, int(before[1]), _ptr(image), _ptr(color), _ptr(depth), _ptr(alpha),
                                                 C.byref(ticket), stream))
                 ctx.pending = _Pending(lib, ticket, capacity, covered, view, n, key, rkey)
                 ctx.instances = None

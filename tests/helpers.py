@@ -83,11 +83,13 @@ def radii_mismatch(hip_radii, pre, tol=2e-3):
     return int((diff & ~near_int & ~near_cull).sum())
 
 
-def assert_grads_flip_aware(hip: dict, ref: dict, tag="", *, bulk_tol=1e-3, max_tol=5e-3, outliers=1e-5):
+def assert_grads_flip_aware(hip: dict, ref: dict, tag="", *, bulk_tol=1e-3, max_tol=5e-3, outliers=4e-6):
     """fp32 kernels vs the fp32 C oracle on LARGE scenes: among millions of gradient elements a handful sit on pixel-splat
     pairs whose threshold decision (alpha >= 1/255, T >= 1e-4) flips between the two fp32 evaluations, which moves them by a
     discrete amount.  Every element within `max_tol` of the tensor's maximum (the flip-aware bound of the fp64 comparisons),
-    all but a fraction `outliers` within `bulk_tol` (the bound of the small-scene fp32 comparisons), median <= 1e-6."""
+    all but a fraction `outliers` within `bulk_tol` (the bound of the small-scene fp32 comparisons), median <= 1e-6.
+    Observed at the headline size on MI355X (round 5, gpurun_out/parity_observed.jsonl): largest element 2.0e-3 of the tensor's
+    maximum, 3.3e-7 of the elements beyond 1e-3 -- the defaults are ~2.5 x / ~12 x that (rounds 1-4 allowed 1e-5 outliers)."""
     for k in ref:
         b = ref[k].double()
         err = (hip[k].double() - b).abs() / b.abs().max().clamp_min(1e-30)

@@ -75,6 +75,11 @@ def test_two_rank_line_carries_the_exchange_diagnostics(hip_device, mode):
     assert abs(pr["link_peak"]["exchange_ms"] - pr["wire_bytes_per_gpu"] / (7 * 153e9) * 1e3) < 1e-9
     assert 1.0 < pr["rccl_typical"]["speedup"] <= pr["one_way_peak"]["speedup"] <= pr["link_peak"]["speedup"] <= 8.0
     assert "2" in ex["predicted_by_world"]
+    # the measured bus bandwidth of the exchange's two collectives rides beside the prediction
+    probe = ex["collective_probe"]
+    assert probe["all_gather_colour_gradients"]["bus_GBps"] > 0 and probe["all_reduce_geometric_gradients"]["bus_GBps"] > 0
+    assert probe["all_gather_colour_gradients"]["wire_bytes_per_gpu"] == 0.5 * 2 * 20000 * 12
+    assert ex["window_bus_GBps"] > 0
     assert ex["exchange_ms"] > 0.0 and 0.0 <= ex["overlap_ms"] <= ex["exchange_ms"]
     assert abs(ex["compute_ms"] - (d["ms_per_step_median"] - ex["exchange_ms"] + ex["overlap_ms"])) < 1e-9
     # ring model at 2 ranks: all-reduce of S moves S per GPU, all-gather / all-to-all of S in total S / 2

@@ -31,11 +31,15 @@ def compare_with_c_oracle(sp, st, grads, dev, use_sh, grad_tol=2e-3, tag="config
     # ceil(3 sqrt(lambda)) of two fp32 implementations may differ by one where the argument is within an ulp of an integer
     dr = (out["radii"].long() - ref["radii"].long()).abs()
     assert int((dr > 0).sum()) <= max(2, int(1e-5 * dr.numel())) and int(dr.max()) <= 1
+    # Bounds = at most ~10 x what these comparisons observe on MI355X (round 5, gpurun_out/parity_observed.jsonl, 15 views of
+    # configs[1], [2], [4]): median relative error <= 9.1e-7, share of pixels above 1e-4 (threshold flips between two fp32
+    # evaluations) <= 1.3e-4, largest absolute error 1.4e-2 (depth image); gradients: largest element error 4.7e-3 of the
+    # tensor's maximum, L2 error <= 5.4e-4, share of elements beyond 2e-3 <= 1e-5.  (Rounds 1-4: 2e-5 / 2e-3 / 5e-2.)
     for k in ("color", "depth", "alpha"):
         a, b = out[k].double(), ref[k].double()
         rel = (a - b).abs() / b.abs().clamp_min(1e-3)
-        assert rel.median().item() < 2e-5, k
-        assert (rel > 1e-4).float().mean().item() < 2e-3, k  # two fp32 implementations: a few threshold flips
+        assert rel.median().item() < 1e-5, k
+        assert (rel > 1e-4).float().mean().item() < 1e-3, k  # two fp32 implementations: a few threshold flips
         assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
     for k in cg:
         a, b = g[k].double(), cg[k].double()
@@ -44,7 +48,7 @@ def compare_with_c_oracle(sp, st, grads, dev, use_sh, grad_tol=2e-3, tag="config
         scale = b.abs().max().item()
         assert ((a - b).norm() / b.norm()).item() <= 1e-3, (k, ((a - b).norm() / b.norm()).item())
         assert ((a - b).abs() > grad_tol * scale).float().mean().item() <= 1e-4, k
-        assert grad_error(g[k], cg[k]) <= 5e-2, (k, grad_error(g[k], cg[k]))
+        assert grad_error(g[k], cg[k]) <= 2.5e-2, (k, grad_error(g[k], cg[k]))
     return out
 
 

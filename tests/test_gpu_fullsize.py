@@ -75,7 +75,7 @@ def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, s
     two fp32 evaluations may differ by one blended pair: <= 2e-2); gradients: among the 3-48 million elements of a tensor a
     handful sit on pixel-splat pairs whose threshold decision flips between the two fp32 evaluations, which moves them by a
     discrete amount -- every element within 5e-3 of the tensor's maximum (the flip-aware bound of the fp64 comparisons),
-    and all but 1e-5 of them within 1e-3 (the bound of the small-scene fp32 comparisons)."""
+    and all but 4e-6 of them within 1e-3 (observed 3.3e-7; the bound of the small-scene fp32 comparisons)."""
     import os
     from oracle import c_oracle
     sp, cam, st, grads = scene

@@ -25,7 +25,7 @@ STAGE_OF = [
     ("sr::k_preprocess_backward", "preprocess_backward"),
     ("sr::k_preprocess", "preprocess"),
     ("sr::k_count_tiles", "scan"),
-    ("sr::k_colscan_local", "scan"),
+    ("sr::k_colscan", "scan"),
     ("sr::k_scan_small", "scan"),
     ("sr::k_emit", "emit"),
     ("sr::k_sort_tiles", "sort_tiles"),
