@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -20,6 +22,8 @@ int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     return fail(std::string(what) + ": " + hipGetErrorString(e));
 }
+
+#define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
 // ---- optional per-stage timing (HIP events on the launch stream) ----
 struct ProfRec { int stage; hipEvent_t a, b; bool ended; unsigned long long serial; };
@@ -54,38 +58,69 @@ struct StageTimer {
     }
 };
 
-// Pinned word + event per (host thread, device) for the asynchronous instance-count read-back of sr_forward
-// (the only state the library keeps besides the profiling counters; created lazily, a few bytes each).  Thread-local, so
-// host threads that drive different streams of one device do not share the read-back word.
-struct HostSync { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; };
-thread_local HostSync g_sync[64];
+// ---- status blocks: how the instance count of a forward reaches the host ------------------------------------------------
+// A pinned, COHERENT 64-byte block of host memory: k_scan_small stores the instance count and the longest list into words 0 / 1
+// and then -- system-scope release stores -- the block's current sequence number into words 2 / 3.  The host polls those two
+// words: nothing is enqueued in the stream for the read-back (rounds 1-3: a copy command; round 4: an event record, which still
+// cost the stream ~8 us between k_scan_small and the scatter -- rocprofv3 kernel trace, profiles/r05_v1_*).
+// sr_forward keeps one block per (host thread, device); sr_forward_async hands one out per forward in flight (a "ticket",
+// pooled per device under a mutex).  A few bytes each, created lazily.
+struct StatusBlock { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; uint32_t seq = 0; hipStream_t stream = nullptr; int dev = 0; };
+typedef StatusBlock HostSync;
+typedef StatusBlock Ticket;
+thread_local StatusBlock g_sync[64];
+std::mutex g_ticket_mutex;
+std::vector<StatusBlock*> g_ticket_free[64];
+// diagnostics (sr_debug_counters): [0] host waits inside sr_forward, [1] sr_forward_async calls, [2] ticket redemptions that
+// found stage 1 still running (the host had to wait), [3] tickets ever created
+std::atomic<long long> g_counters[4];
+
+int status_block_init(StatusBlock& b, int dev) {
+    // coherent (fine-grained) host memory: the kernel's stores become visible to the host while the stream keeps running
+    if (hipHostMalloc(reinterpret_cast<void**>(&b.pinned), 64, hipHostMallocCoherent) != hipSuccess &&
+        hipHostMalloc(reinterpret_cast<void**>(&b.pinned), 64, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, b.pinned, 0) != hipSuccess) { hipHostFree(b.pinned); b.pinned = nullptr; return fail("hipHostGetDevicePointer failed"); }
+    b.pinned_dev = static_cast<uint32_t*>(dp);
+    for (int i = 0; i < 16; ++i) b.pinned[i] = 0u;
+    b.dev = dev; b.seq = 0;
+    return 0;
+}
+// a new use of the block: the sequence number the kernel will publish (never 0)
+uint32_t status_block_arm(StatusBlock& b, hipStream_t st) {
+    b.seq = b.seq + 1u == 0u ? 1u : b.seq + 1u;
+    b.stream = st;
+    return b.seq;
+}
+// Waits until both words of the armed use have arrived.  *waited = the first look found them missing.  Polls (the data arrives
+// while the stream runs); after two seconds without it falls back to draining the stream, which also surfaces a failed launch.
+int status_block_wait(StatusBlock& b, bool* waited) {
+    volatile uint32_t* p = b.pinned;
+    auto ready = [&] { return p[2] == b.seq && p[3] == b.seq; };
+    if (waited) *waited = false;
+    if (!ready()) {
+        if (waited) *waited = true;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !ready(); ++spins) {
+            if (spins > 4096u) std::this_thread::yield();
+            if ((spins & 0xfffu) == 0xfffu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                SR_TRY(check_hip(hipStreamSynchronize(b.stream), "wait for the instance count"));
+                if (!ready()) return fail("the instance count of the forward never reached the host (k_scan_small did not run?)");
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
 
 int get_host_sync(HostSync** out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail("hipGetDevice failed");
-    HostSync& h = g_sync[dev];
-    if (!h.pinned) {
-        // coherent (fine-grained) host memory: k_scan_small stores the two counters straight into it
-        if (hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocCoherent) != hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) return fail("hipHostMalloc failed");
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, h.pinned, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed");
-        h.pinned_dev = static_cast<uint32_t*>(dp);
-        if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
-    }
+    StatusBlock& h = g_sync[dev];
+    if (!h.pinned) SR_TRY(status_block_init(h, dev));
     *out = &h;
     return 0;
 }
-
-// ---- tickets of sr_forward_async ----------------------------------------------------------------------------------------
-// One pinned, coherent 64-byte block (k_scan_small stores the instance count and the longest list into it) and one event
-// (recorded behind stage 1) per forward in flight; pooled per device under a mutex, a few bytes each.
-struct Ticket { uint32_t* pinned = nullptr; uint32_t* pinned_dev = nullptr; hipEvent_t ev = nullptr; int dev = 0; };
-std::mutex g_ticket_mutex;
-std::vector<Ticket*> g_ticket_free[64];
-// diagnostics (sr_debug_counters): [0] host waits inside sr_forward, [1] sr_forward_async calls, [2] ticket redemptions that
-// found stage 1 still running (the host had to wait), [3] tickets ever created
-std::atomic<long long> g_counters[4];
 
 int ticket_acquire(Ticket** out) {
     int dev = 0;
@@ -94,14 +129,8 @@ int ticket_acquire(Ticket** out) {
         std::lock_guard<std::mutex> lock(g_ticket_mutex);
         if (!g_ticket_free[dev].empty()) { *out = g_ticket_free[dev].back(); g_ticket_free[dev].pop_back(); return 0; }
     }
-    Ticket* t = new Ticket;
-    t->dev = dev;
-    if (hipHostMalloc(reinterpret_cast<void**>(&t->pinned), 64, hipHostMallocCoherent) != hipSuccess &&
-        hipHostMalloc(reinterpret_cast<void**>(&t->pinned), 64, hipHostMallocDefault) != hipSuccess) { delete t; return fail("hipHostMalloc failed"); }
-    void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, t->pinned, 0) != hipSuccess) { hipHostFree(t->pinned); delete t; return fail("hipHostGetDevicePointer failed"); }
-    t->pinned_dev = static_cast<uint32_t*>(dp);
-    if (hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) { hipHostFree(t->pinned); delete t; return fail("hipEventCreate failed"); }
+    StatusBlock* t = new StatusBlock;
+    if (int rc = status_block_init(*t, dev)) { delete t; return rc; }
     g_counters[3].fetch_add(1, std::memory_order_relaxed);
     *out = t;
     return 0;
@@ -117,7 +146,6 @@ std::atomic<int> g_bwd_kernel{[] {
     return !sel ? 0 : (std::string(sel) == "wave" ? 1 : ((std::string(sel) == "quads" || std::string(sel) == "mfma") ? 2 : 0));
 }()};
 
-#define SR_TRY(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
 
 // ---- debug = true: input snapshot on a failed launch ------------------------------------------------------------------
 // [EXT] with `debug` set synchronises after every kernel and, when one fails, dumps the call's arguments to
@@ -253,15 +281,15 @@ size_t sr_backward_scratch_bytes(long long r) {
 namespace {
 
 int launch_stage1(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, int* radii, uint32_t* host_out,
-                  hipStream_t st) {
+                  uint32_t host_seq, hipStream_t st) {
     { StageTimer t_(0, st); sr::launch_preprocess(v, s, g, radii, st); }
     SR_TRY(after_launch(view, st, "preprocess"));
-    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, host_out, st); }
+    { StageTimer t_(1, st); sr::launch_count_tiles(v, s.N, g, st); sr::launch_scan_small(v, s.N, g, host_out, host_seq, st); }
     SR_TRY(after_launch(view, st, "scan"));
     return 0;
 }
 
-// hs != nullptr: the instance count / longest list were copied to hs->pinned and hs->ev recorded; the host waits for
+// hs != nullptr: k_scan_small stores the instance count / longest list into hs->pinned (status block above); the host waits for
 // them after launching the scatter (the GPU keeps working) and then launches only the sort classes that are needed.
 // hs == nullptr: nobody waits; `max_len` = the longest list the sort classes must cover (< 0: launch every class).
 int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, const sr::Geom& g, const sr::Binning& b,
@@ -271,7 +299,7 @@ int launch_stage2(const SrView* view, const sr::ViewK& v, const sr::SplatsK& s, 
     SR_TRY(after_launch(view, st, "emit"));
     if (hs) {
         g_counters[0].fetch_add(1, std::memory_order_relaxed);
-        SR_TRY(check_hip(hipEventSynchronize(hs->ev), "wait for instance count"));
+        SR_TRY(status_block_wait(*hs, nullptr));
         max_len = (long long)hs->pinned[1];
         // the binning buffer is too small: the scatter just launched exits on its own, and nothing else of stage 2 is worth
         // launching -- the caller re-runs it with a buffer that fits (SR_NEED_CAPACITY)
@@ -300,7 +328,7 @@ int sr_forward_prepare(const SrView* view, const SrSplats* splats, void* geom, i
     sr::carve_geom(geom, s.N, v.H, v.W, &g);
     HostSync* hs = nullptr;
     SR_TRY(get_host_sync(&hs));
-    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));
+    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, status_block_arm(*hs, st), st));
     SR_TRY(check_hip(hipStreamSynchronize(st), "sync after prepare"));
     *instances_out = (long long)hs->pinned[0];
     return 0;
@@ -322,8 +350,7 @@ int sr_forward(const SrView* view, const SrSplats* splats, void* geom, int* radi
     sr::carve_image(image, v.H, v.W, &im);
     HostSync* hs = nullptr;
     SR_TRY(get_host_sync(&hs));
-    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, st));   // k_scan_small stores the two counters into hs->pinned
-    SR_TRY(check_hip(hipEventRecord(hs->ev, st), "record"));
+    SR_TRY(launch_stage1(view, v, s, g, radii, hs->pinned_dev, status_block_arm(*hs, st), st));   // k_scan_small stores the counters into hs->pinned
     SR_TRY(launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, hs, -1, -1, st));  // waits inside, GPU busy
     const long long total = (long long)hs->pinned[0];
     *instances_out = total;
@@ -368,9 +395,7 @@ int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int
     b.sorted_up_to = covered < 0 ? 0xffffffffu : (uint32_t)covered;
     Ticket* t = nullptr;
     SR_TRY(ticket_acquire(&t));
-    t->pinned[0] = 0u; t->pinned[1] = 0u;
-    int rc = launch_stage1(view, v, s, g, radii, t->pinned_dev, st);
-    if (!rc) rc = check_hip(hipEventRecord(t->ev, st), "record");
+    int rc = launch_stage1(view, v, s, g, radii, t->pinned_dev, status_block_arm(*t, st), st);
     if (!rc) rc = launch_stage2(view, v, s, g, b, im, out_color, out_depth, out_alpha, nullptr, covered,
                                 longest_list_expected >= 0 && longest_list_expected <= longest_list_hint ? longest_list_expected : -1, st);
     if (rc) {   // nothing of this call may still write the block when it is handed out again
@@ -386,12 +411,9 @@ int sr_forward_async(const SrView* view, const SrSplats* splats, void* geom, int
 int sr_ticket_wait(void* ticket, long long* instances_out, long long* longest_list_out) {
     if (!ticket) return fail("null ticket");
     Ticket* t = static_cast<Ticket*>(ticket);
-    const hipError_t q = hipEventQuery(t->ev);
-    if (q == hipErrorNotReady) {
-        (void)hipGetLastError();
-        g_counters[2].fetch_add(1, std::memory_order_relaxed);
-    }
-    const int rc = check_hip(hipEventSynchronize(t->ev), "wait for the ticket of sr_forward_async");
+    bool waited = false;
+    const int rc = status_block_wait(*t, &waited);
+    if (waited) g_counters[2].fetch_add(1, std::memory_order_relaxed);
     if (instances_out) *instances_out = (long long)t->pinned[0];
     if (longest_list_out) *longest_list_out = (long long)t->pinned[1];
     ticket_recycle(t);

@@ -138,7 +138,7 @@ void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st) {
 //          accumulated tile_count) -> tile_start[tiles+1];
 //          clears tile_cursor
 __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, int n_tiles, const Chunking ch, int use_matrix,
-                                                      uint32_t* __restrict__ host_out) {
+                                                      uint32_t* __restrict__ host_out, uint32_t host_seq) {
     __shared__ uint32_t s_wave[16];
     const bool tiles = blockIdx.x == 1;
     uint32_t* dst = tiles ? g.tile_start : g.block_offsets;
@@ -181,16 +181,30 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
         __syncthreads();
     }
     const bool in_regs = n <= 1024 * kPer;   // uniform
+    // host_out: pinned, coherent host memory: [0] instance count, [1] longest list, [2] / [3] = host_seq once [0] / [1] are
+    // there (system-scope release stores: the host POLLS the two flags -- no event, no copy command in the stream; round 5: an
+    // event record between this kernel and the scatter cost the stream 8 us).  Earlier text:
     // host_out: two words of pinned host memory (sr_forward's instance count / longest list read-back): stored from here,
     // the host reads them after the event that follows this kernel -- no copy command in the stream
-    if (tid == 0) { if (tiles) dst[n] = carry; else { g.total[0] = carry; if (host_out) host_out[0] = carry; } }
+    if (tid == 0) {
+        if (tiles) dst[n] = carry;
+        else {
+            g.total[0] = carry;
+            if (host_out) { host_out[0] = carry; __hip_atomic_store(host_out + 2, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+    }
     if (tiles) {  // longest tile list: lets the host skip the launches of the rare long-list sort classes
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, d, 64));
         __syncthreads();
         if (lane == 0) s_wave[w] = vmax;
         __syncthreads();
-        if (tid == 0) { uint32_t m = 0; for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]); g.total[1] = m; s_wave[0] = m; if (host_out) host_out[1] = m; }
+        if (tid == 0) {
+            uint32_t m = 0;
+            for (int k = 0; k < 16; ++k) m = max(m, s_wave[k]);
+            g.total[1] = m; s_wave[0] = m;
+            if (host_out) { host_out[1] = m; __hip_atomic_store(host_out + 3, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
         __syncthreads();
         // Launch order of the blend kernels: longest lists first (longest-processing-time-first keeps the tail of the
         // launch short: 2500 tiles are only ~1.6 rounds of resident workgroups).  Counting sort into 256 linear length
@@ -247,10 +261,10 @@ __global__ void __launch_bounds__(1024) k_scan_small(const Geom g, int n_sub, in
     }
 }
 
-void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, hipStream_t st) {
+void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, uint32_t host_seq, hipStream_t st) {
     const Chunking ch = make_chunking(N, v.gx * v.gy);
     hipLaunchKernelGGL(k_scan_small, dim3(2), dim3(1024), 0, st, g, (N + kBlock - 1) / kBlock, v.gx * v.gy, ch,
-                       use_count_matrix(v) ? 1 : 0, host_out);
+                       use_count_matrix(v) ? 1 : 0, host_out, host_seq);
 }
 
 // ---- emit instances straight into their tile's segment -------------------------------------

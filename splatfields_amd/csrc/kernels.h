@@ -28,7 +28,7 @@ void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g,
 // true when the image is small enough for the atomic-free count-matrix bucketing
 inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixTiles; }
 void launch_count_tiles(const ViewK& v, int N, const Geom& g, hipStream_t st);
-void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, hipStream_t st);
+void launch_scan_small(const ViewK& v, int N, const Geom& g, uint32_t* host_out, uint32_t host_seq, hipStream_t st);
 void launch_emit(const ViewK& v, int N, const Geom& g, const Binning& b, hipStream_t st);
 void launch_sort_tiles(const ViewK& v, const Geom& g, const Binning& b, long long max_len, long long expected_len, hipStream_t st);
 // render.hip
