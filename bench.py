@@ -707,7 +707,8 @@ def main():
             torch.cuda.empty_cache()
             # 16 warmup steps = two cycles of the 8 views: a buffer size learned from the last view of the first cycle is allocated in
             # the second one, not in the first timed step (one ~80 ms hipMalloc pair in 20 steps made the mean 4.3 ms beside a 0.53 ms median)
-            r = time_plain_workload(n_, w_, h_, sh_, ms_, args.sh_degree, 20, 16, dev)
+            # (round 5: + 32 -- six cycles in all, as for the headline: a 10 ms region needs ~25 ms of the workload in front of it)
+            r = time_plain_workload(n_, w_, h_, sh_, ms_, args.sh_degree, 20, 16 + 32, dev)
             r["name"] = name
             out["other_workloads"].append(r)
             progress(f"workload '{name}' done")
