@@ -137,7 +137,15 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     __shared__ ushort4 s_rect[COUNT_ATOMIC ? kBlock : 1];
     __shared__ float4 s_r0[COUNT_ATOMIC ? kBlock : 1], s_r1[COUNT_ATOMIC ? kBlock : 1];   // ellipses for the tile_reached test
     __shared__ uint32_t s_scan[8];
-    __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
+#ifndef SR_PRE_REC_T
+#define SR_PRE_REC_T 1   // 1: the 64-byte records leave through LDS, quarter-major with a padded row: consecutive lanes store
+#endif                   //    consecutive 16-byte pieces of the workgroup's contiguous 16 KB (whole lines per wave-instruction);
+                         //    0: every thread stores its own four quarters (16-byte pieces at a 64-byte stride: the L2 has to
+                         //    assemble every line from four partial writes; rounds 1-4)
+    constexpr int kRecRow = kBlock + 1;   // float4 per quarter row: + 1 keeps the transposed reads off each other's banks
+    constexpr int kRecF4 = SR_PRE_REC_T ? 4 * kRecRow : 1;
+    __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : kRecF4];   // SH staging first; the records' transpose afterwards
+    static_assert(!STAGE_SH || kBlock * kShRowF4 >= kRecF4, "the record transpose reuses the SH staging area");
 
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     const float* vm = v.viewmatrix;
@@ -313,7 +321,26 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     uint32_t total;
     const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
+#if SR_PRE_REC_T
+    {
+        // (block_exclusive_scan's barriers lie behind every thread's last read of the SH rows: the area is free)
+        float4* s_rec = s_sh;
+        const float4 q3 = make_float4(__uint_as_float(rect_bits), __uint_as_float((uint32_t)(rect.z - rect.x)), __uint_as_float(excl), 0.f);
+        // a splat without a record (culled, or no tile) stores the "never visible" defaults: nothing ever gathers its record
+        s_rec[threadIdx.x] = ell0; s_rec[kRecRow + threadIdx.x] = ell1; s_rec[2 * kRecRow + threadIdx.x] = rec2; s_rec[3 * kRecRow + threadIdx.x] = q3;
+        __syncthreads();
+        const int n_here = min(kBlock, s.N - (int)blockIdx.x * kBlock);
+        float4* out = g.rec + 4 * (size_t)blockIdx.x * kBlock;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int G = j * kBlock + (int)threadIdx.x;       // float4 index inside the workgroup's block: record G / 4, quarter G % 4
+            if (G < 4 * n_here) out[G] = s_rec[(G & 3) * kRecRow + (G >> 2)];
+        }
+    }
+    if (false) {
+#else
     if (write_rec) {
+#endif
         // The 64-byte record, written whole (a line with a 16-byte hole leaves the L2 as a masked partial write, which costs
         // more than the 16 bytes: 0.087 -> 0.078 ms for this kernel).  q3 = (tile rect origin, rect width, first instance of
         // the splat RELATIVE to its 256-splat sub-batch, 0): the backward blend derives a (splat, tile) pair's instance index
@@ -403,7 +430,17 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                                                                 const int first_splat, const int end_splat) {
     // splats [first_splat, end_splat) of the cloud (first_splat a multiple of 256): the whole cloud in one launch, or one
     // slice of it per launch when the caller overlaps an exchange of the finished slices with the rest (sr_backward_splats)
-    __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
+#ifndef SR_PREB_T3
+#define SR_PREB_T3 0   // 1: the three [N,3] gradient tensors (means3D, means2D, scales) leave through LDS as whole 16-byte pieces of
+#endif                 //    the workgroup's contiguous 3 KB blocks (needs 16-byte aligned tensors); 0: three 4-byte stores at a
+                       //    12-byte stride per tensor and thread (every line assembled by the L2 from three partial writes).
+                       //    Measured in round 5 (same box, alternated three times): 0.1038 vs 0.0955 ms, SLOWER (precomputed
+                       //    colours 0.0513 vs 0.0491): the transpose has to wait for the SH gradient to leave the staging area
+                       //    (two more barriers), so the small stores move from the middle of the workgroup's life -- where they
+                       //    overlapped the 48 KB stage-out -- to its very end.  The same idea in k_preprocess (SR_PRE_REC_T,
+                       //    64-byte records at a 64-byte stride -> whole lines) sits at the end of the kernel anyway and gains 3 us
+    constexpr int kT3Floats = SR_PREB_T3 ? 3 * 3 * kBlock : 4;
+    __shared__ __attribute__((aligned(16))) float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : (kT3Floats + 3) / 4];
     const int idx = first_splat + blockIdx.x * kBlock + threadIdx.x;
     const bool valid = idx < end_splat;
     int radius_in = 0;
@@ -479,16 +516,16 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             }
         }
     }
+    float3 d_mean = make_float3(0.f, 0.f, 0.f);
+    float3 d_scale = make_float3(0.f, 0.f, 0.f);
+    float2 d_m2d = make_float2(0.f, 0.f);
     if (valid) {
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
     const int K = v.sh_coeffs;
 
-    float3 d_mean = make_float3(0.f, 0.f, 0.f);
-    float3 d_scale = make_float3(0.f, 0.f, 0.f);
     float4 d_rot = make_float4(0.f, 0.f, 0.f, 0.f);
     float d_opac = 0.f;
-    float2 d_m2d = make_float2(0.f, 0.f);
     float3 d_rgb = make_float3(0.f, 0.f, 0.f);
     float d_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool visible = radius_in > 0;
@@ -664,10 +701,12 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }
     if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
 
+#if !SR_PREB_T3
     gr.means3D[3 * idx] = d_mean.x; gr.means3D[3 * idx + 1] = d_mean.y; gr.means3D[3 * idx + 2] = d_mean.z;
     gr.means2D[3 * idx] = d_m2d.x; gr.means2D[3 * idx + 1] = d_m2d.y; gr.means2D[3 * idx + 2] = 0.f;
-    gr.opacity[idx] = d_opac;
     if (gr.scales) { gr.scales[3 * idx] = d_scale.x; gr.scales[3 * idx + 1] = d_scale.y; gr.scales[3 * idx + 2] = d_scale.z; }
+#endif
+    gr.opacity[idx] = d_opac;
     if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
     }  // valid
@@ -677,6 +716,32 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
         else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
     }
+#if SR_PREB_T3
+    {
+        // [N,3] tensors: thread t's three floats at floats 3t .. 3t + 2 of the workgroup's block (a 12-byte stride: conflict-free
+        // in LDS), read back as float4 by consecutive lanes.  The staging area doubles as the transpose buffer once the SH
+        // gradient has left it.
+        if constexpr (STAGE_SH && !SH_TO_COLORS) __syncthreads();
+        float* s_t = reinterpret_cast<float*>(s_sh);
+        const int t = (int)threadIdx.x;
+        s_t[3 * t] = d_mean.x; s_t[3 * t + 1] = d_mean.y; s_t[3 * t + 2] = d_mean.z;
+        s_t[3 * kBlock + 3 * t] = d_m2d.x; s_t[3 * kBlock + 3 * t + 1] = d_m2d.y; s_t[3 * kBlock + 3 * t + 2] = 0.f;
+        s_t[6 * kBlock + 3 * t] = d_scale.x; s_t[6 * kBlock + 3 * t + 1] = d_scale.y; s_t[6 * kBlock + 3 * t + 2] = d_scale.z;
+        __syncthreads();
+        const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
+        const int total_f = 3 * min(kBlock, end_splat - (int)first);   // floats of this workgroup's block in every [N,3] tensor
+        float* dst3[3] = {gr.means3D + 3 * first, gr.means2D + 3 * first, gr.scales ? gr.scales + 3 * first : nullptr};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (!dst3[a]) continue;
+            const int f0 = 4 * t;
+            if (f0 >= total_f) continue;
+            const float4 x = *reinterpret_cast<const float4*>(s_t + a * 3 * kBlock + f0);
+            if (f0 + 3 < total_f) *reinterpret_cast<float4*>(dst3[a] + f0) = x;
+            else { dst3[a][f0] = x.x; if (f0 + 1 < total_f) dst3[a][f0 + 1] = x.y; if (f0 + 2 < total_f) dst3[a][f0 + 2] = x.z; }
+        }
+    }
+#endif
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
