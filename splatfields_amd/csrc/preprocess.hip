@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     float3 p = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
     float opac_in = 0.f;
+    float3 col_in = make_float3(0.f, 0.f, 0.f);
     if (idx < s.N) {
         p = make_float3(s.means3D[3 * idx], s.means3D[3 * idx + 1], s.means3D[3 * idx + 2]);
         opac_in = s.opacities[idx];
@@ -167,6 +168,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
             q_in = reinterpret_cast<const float4*>(s.rotations)[idx];
             sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
         }
+        // (round 5) precomputed colours too: requested where they were used -- behind the projection -- they were a second memory
+        // round trip in the middle of every workgroup's life (-0.6 us).  Only in the variants without SH staging: the same three
+        // registers held across the staging of the SH path cost that kernel 3 us (measured).
+        if constexpr (!STAGE_SH) { if (s.colors) col_in = make_float3(s.colors[3 * idx], s.colors[3 * idx + 1], s.colors[3 * idx + 2]); }
     }
     if constexpr (STAGE_SH) {
         const size_t first = (size_t)blockIdx.x * kBlock;
@@ -243,7 +248,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
 
                     float3 rgb;
                     if (s.colors) {
-                        rgb = make_float3(s.colors[3 * idx], s.colors[3 * idx + 1], s.colors[3 * idx + 2]);
+                        if constexpr (STAGE_SH) rgb = make_float3(s.colors[3 * idx], s.colors[3 * idx + 1], s.colors[3 * idx + 2]);
+                        else rgb = col_in;
                     } else {
                         const float* cp = v.campos;
                         float3 d = make_float3(p.x - cp[0], p.y - cp[1], p.z - cp[2]);
@@ -460,35 +466,63 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             sc_in = make_float3(s.scales[3 * idx], s.scales[3 * idx + 1], s.scales[3 * idx + 2]);
         }
     }
+    // the colour / direction Jacobian of the forward (SH path): requested with the other per-splat inputs, not where it is used --
+    // behind the slot reduction and the covariance chain it was one more memory round trip at the end of the kernel
+    float4 jac0 = make_float4(0.f, 0.f, 0.f, 0.f), jac1 = jac0;
+    float jac22 = 0.f;
+    if (valid && (gr.shs || SH_TO_COLORS) && v.sh_degree > 0) {
+        const float4* jq = reinterpret_cast<const float4*>(g.dcol_ddir);
+        jac0 = jq[idx]; jac1 = jq[(size_t)s.N + idx];
+        jac22 = g.dcol_ddir[(size_t)8 * s.N + idx];
+    }
     float q_norm = 1.0f;
     if (s.raw) activate_inputs(s.raw, sc_in, opac_in, q_in, q_norm);
     // Which of the splat's instances hold a gradient slot: the backward blend wrote one (and set the instance's `reached` byte)
     // for every list entry in front of the stop of its tile's last pixel; the others are neither written nor read.  The bytes
     // of the first 4 instances are requested now, together with the splat's own loads (most splats have <= 4 instances).
-    const bool vis_in = valid && radius_in > 0;
+#ifndef SR_PREB_DIAG
+#define SR_PREB_DIAG 0   // timing experiments (wrong results): 1 no `reached` / slot reads, 2 no SH-gradient stage-out, 4 no small stores
+#endif
+    const bool vis_in = valid && radius_in > 0 && !(SR_PREB_DIAG & 1);
+#ifndef SR_PREB_SPEC
+#define SR_PREB_SPEC 1   // 1: the gradient slots of a splat's first four instances are requested TOGETHER with their `reached` bytes,
+#endif                   //    before anything looks at the bytes (one memory round trip instead of two: offsets -> {reached, slots}
+                         //    instead of offsets -> reached -> slots); a slot the backward blend did not write holds stale bytes and
+                         //    is dropped by its byte.  0: slots requested once their byte is known (rounds 3-4).
+                         //    Round 5, same box, alternated: 0.0941 -> 0.0857 ms.  (A first version issued the slot requests BEHIND
+                         //    the or-ing of the bytes, i.e. behind the wait for them, and measured nothing: the kernel is a chain of
+                         //    dependent memory round trips per workgroup -- timing builds without the slot reads, without the SH
+                         //    stage-out and without the small stores take 0.067 / 0.068 / 0.088 ms: the parts ADD, three workgroups
+                         //    per CU do not overlap them -- and every round trip taken out of the chain is time.)
     uint32_t reached4 = 0u;
+#if SR_PREB_SPEC
+    float4 spec[4][3];
+    {
+        // branch-free inside the guard: positions beyond the splat's last instance re-request the last one (its line is there)
+        uint32_t rb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) spec[i][0] = spec[i][1] = spec[i][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vis_in && cnt_in > 0u) {
+            const float4* sl0 = reinterpret_cast<const float4*>(slots) + (size_t)first_in * kSlotF4;
+            const uint32_t lasti = min(cnt_in, 4u) - 1u;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) rb[i] = reached[first_in + min(i, lasti)];
+            if (cnt_in < 32u) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    const uint32_t j = min(i, lasti);
+                    spec[i][0] = sl0[kSlotF4 * j]; spec[i][1] = sl0[kSlotF4 * j + 1]; spec[i][2] = sl0[kSlotF4 * j + 2];
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) if (i <= lasti) reached4 |= rb[i] << (8 * i);
+        }
+    }
+#else
     if (vis_in) {
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i)
             if (i < cnt_in) reached4 |= (uint32_t)reached[first_in + i] << (8 * i);
-    }
-#ifndef SR_PREB_SPEC
-#define SR_PREB_SPEC 0   // 1: the gradient slots of a splat's first four instances are requested TOGETHER with their `reached` bytes
-#endif                   //    (one memory round trip instead of two: offsets -> {reached, slots} instead of offsets -> reached ->
-                         //    slots); a slot the backward blend did not write holds stale bytes and is dropped by the byte.
-                         //    0: slots requested once their byte is known.
-                         //    Measured in round 5 (same box, alternated): 0.0967 vs 0.0959 ms at the headline, 0.0510 vs 0.0482 with
-                         //    precomputed colours, 0.0785 vs 0.0760 at 100 k x 0.05 -- the kernel is not waiting for that round
-                         //    trip; the 27 % of the slots nobody wrote are extra traffic.  Off
-#if SR_PREB_SPEC
-    float4 spec[4][3];
-    {
-        const float4* sl0 = reinterpret_cast<const float4*>(slots) + (size_t)first_in * kSlotF4;
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i) {
-            spec[i][0] = spec[i][1] = spec[i][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vis_in && cnt_in < 32u && i < cnt_in) { spec[i][0] = sl0[kSlotF4 * i]; spec[i][1] = sl0[kSlotF4 * i + 1]; spec[i][2] = sl0[kSlotF4 * i + 2]; }
-        }
     }
 #endif
     // ---- segmented reduction of every splat's instance slots (fixed order -> deterministic) ----
@@ -706,9 +740,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
             if (v.sh_degree > 0) {
                 // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
-                const float4* jq = reinterpret_cast<const float4*>(g.dcol_ddir);
-                const float4 j0 = jq[idx], j1 = jq[(size_t)s.N + idx];
-                const float j22 = g.dcol_ddir[(size_t)8 * s.N + idx];
+                const float4 j0 = jac0, j1 = jac1;
+                const float j22 = jac22;
                 const float3 dd_ = make_float3(dc.x * j0.x + dc.y * j0.w + dc.z * j1.z,
                                                dc.x * j0.y + dc.y * j1.x + dc.z * j1.w,
                                                dc.x * j0.z + dc.y * j1.y + dc.z * j22);
@@ -733,6 +766,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }
     if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
 
+#if SR_PREB_DIAG & 4
+    if (d_mean.x == 12345.678f)
+#endif
+    {
 #if !SR_PREB_T3
     gr.means3D[3 * idx] = d_mean.x; gr.means3D[3 * idx + 1] = d_mean.y; gr.means3D[3 * idx + 2] = d_mean.z;
     gr.means2D[3 * idx] = d_m2d.x; gr.means2D[3 * idx + 1] = d_m2d.y; gr.means2D[3 * idx + 2] = 0.f;
@@ -741,12 +778,18 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     gr.opacity[idx] = d_opac;
     if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
+    }
     }  // valid
     if constexpr (STAGE_SH && !SH_TO_COLORS) {
         __syncthreads();
         const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
+#if SR_PREB_DIAG & 2
+        if (s_sh[threadIdx.x].x == 12345.678f)
+#endif
+        {
         if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
         else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
+        }
     }
 #if SR_PREB_T3
     {
