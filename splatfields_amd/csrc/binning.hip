@@ -530,8 +530,10 @@ __device__ __forceinline__ void sort_block_lds(const Binning& b, uint32_t first,
 // workload 2500 workgroups each, plus the launch gap, for ~40 % of the tiles).
 __global__ void __launch_bounds__(256) k_sort_tiles_regs(const Geom g, const Binning b) {
     __shared__ uint64_t skey[2048];
-    if (g.total[0] > b.capacity) return;
+    const uint32_t total_instances = g.total[0];
     const uint32_t tile = g.tile_order[blockIdx.x];  // longest lists first
+    asm volatile("" :: "s"(tile));   // requested together with the count above, not behind the early exit (one round trip less per workgroup)
+    if (total_instances > b.capacity) return;
     const uint32_t start = g.tile_start[tile];
     const uint32_t n = g.tile_start[tile + 1] - start;
     if (n == 0u || n > 2048u) return;

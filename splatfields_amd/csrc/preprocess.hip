@@ -585,31 +585,93 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     float3 d_mean = make_float3(0.f, 0.f, 0.f);
     float3 d_scale = make_float3(0.f, 0.f, 0.f);
     float2 d_m2d = make_float2(0.f, 0.f);
+    const bool visible = valid && radius_in > 0;
+    const int K = v.sh_coeffs;
+    const float3 p = visible ? p_in : make_float3(0.f, 0.f, 0.f);
+    const uint8_t flags = visible ? flags_in : (uint8_t)0;
+    float3 d_rgb = visible ? make_float3(sum[6], sum[7], sum[8]) : make_float3(0.f, 0.f, 0.f);
+    float3 dm_dir = make_float3(0.f, 0.f, 0.f);   // dL/dmean through the view direction of the SH colour (added behind the other terms)
+    // ---- colour: SH coefficients and view direction, or precomputed colours ----
+    auto colour_part = [&]() {
+    if (gr.shs || SH_TO_COLORS) {
+        // staged: this thread's LDS row first supplies its SH coefficients, then receives its gradients
+        float *out_lo, *out_hi;   // float j = 3k + c of this splat's SH gradient: out_lo[j] for j < 3, out_hi[j] beyond
+        if (STAGE_SH) sh_row_pointers(s_sh, gr.shs_rest != nullptr, threadIdx.x, out_lo, out_hi);
+        else out_lo = out_hi = gr.shs + (size_t)idx * K * 3;
+        int nb = 0;
+        if (visible) {
+            nb = (v.sh_degree + 1) * (v.sh_degree + 1);
+            float3 dc = d_rgb;
+            if (flags & kFlagClampR) dc.x = 0.f;
+            if (flags & kFlagClampG) dc.y = 0.f;
+            if (flags & kFlagClampB) dc.z = 0.f;
+            const float* cp = v.campos;
+            const float3 dv = make_float3(p.x - cp[0], p.y - cp[1], p.z - cp[2]);
+            const float inv_len = 1.0f / sqrtf(dot3(dv, dv));
+            const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
+            float B[16];
+            sh_basis(v.sh_degree, d, B);
+            if (!SH_TO_COLORS)
+                for (int k = 0; k < nb; ++k) {
+                    float* o = k == 0 ? out_lo : out_hi + 3 * k;
+                    o[0] = B[k] * dc.x; o[1] = B[k] * dc.y; o[2] = B[k] * dc.z;
+                }
+            if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
+            if (v.sh_degree > 0) {
+                // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
+                const float4 j0 = jac0, j1 = jac1;
+                const float j22 = jac22;
+                const float3 dd_ = make_float3(dc.x * j0.x + dc.y * j0.w + dc.z * j1.z,
+                                               dc.x * j0.y + dc.y * j1.x + dc.z * j1.w,
+                                               dc.x * j0.z + dc.y * j1.y + dc.z * j22);
+                // through the normalisation d = dv / |dv|
+                const float proj = dot3(d, dd_);
+                dm_dir = make_float3((dd_.x - d.x * proj) * inv_len, (dd_.y - d.y * proj) * inv_len, (dd_.z - d.z * proj) * inv_len);
+            }
+        }
+        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { float* o = k == 0 ? out_lo : out_hi + 3 * k; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
+    }
+    };
+    auto stage_out_part = [&]() {
+        __syncthreads();
+        const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
+#if SR_PREB_DIAG & 2
+        if (s_sh[threadIdx.x].x == 12345.678f)
+#endif
+        {
+        if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
+        else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
+        }
+    };
+#ifndef SR_PREB_COLFIRST
+#define SR_PREB_COLFIRST 0   // 1: the SH gradient -- 192 of the 248 bytes a splat writes; it needs only the colour sums and the view
+#endif                       //    direction -- is computed, staged and STORED first, and the covariance chain rule runs while those
+                             //    stores drain (stores are fire-and-forget); 0: everything computed, then the store burst at the
+                             //    very end of the workgroup's life.  Measured in round 5 (alternated three times): 0.0837 vs 0.0825
+                             //    ms -- nothing: a wavefront does not wait for its stores anyway, and the CU's other workgroups were
+                             //    already computing beside the burst.  Off
+    constexpr bool kColourFirst = STAGE_SH && !SH_TO_COLORS && SR_PREB_COLFIRST;
+    if constexpr (kColourFirst) {
+        if (valid) colour_part();
+        stage_out_part();
+    }
     if (valid) {
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
-    const int K = v.sh_coeffs;
 
     float4 d_rot = make_float4(0.f, 0.f, 0.f, 0.f);
     float d_opac = 0.f;
-    float3 d_rgb = make_float3(0.f, 0.f, 0.f);
     float d_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool visible = radius_in > 0;
 
-    float3 p = make_float3(0.f, 0.f, 0.f);
-    uint8_t flags = 0;
     if (visible) {
         const float S0 = sum[0], Sx = sum[1], Sy = sum[2], Sxx = sum[3], Sxy = sum[4], Syy = sum[5];
-        const float dr = sum[6], dg = sum[7], db = sum[8], dd = sum[9];
-        flags = flags_in;
+        const float dd = sum[9];
         const float o = opac_in;
         // the six geometric sums arrive multiplied by the opacity (k_render_backward accumulates o G dL/dalpha)
         d_opac = o > 0.0f ? S0 / o : 0.0f;
-        d_rgb = make_float3(dr, dg, db);
         // conic gradients; .y is half of the true dL/dB (off-diagonal counted once, used twice below)
         const float dcon_x = -0.5f * Sxx, dcon_y = -0.5f * Sxy, dcon_z = -0.5f * Syy;
 
-        p = p_in;
         const float3 pv = make_float3(vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12],
                                       vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13],
                                       vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14]);
@@ -713,47 +775,8 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         }
     }
 
-    // ---- colour: SH coefficients and view direction, or precomputed colours ----
-    if (gr.shs || SH_TO_COLORS) {
-        // staged: this thread's LDS row first supplies its SH coefficients, then receives its gradients
-        float *out_lo, *out_hi;   // float j = 3k + c of this splat's SH gradient: out_lo[j] for j < 3, out_hi[j] beyond
-        if (STAGE_SH) sh_row_pointers(s_sh, gr.shs_rest != nullptr, threadIdx.x, out_lo, out_hi);
-        else out_lo = out_hi = gr.shs + (size_t)idx * K * 3;
-        int nb = 0;
-        if (visible) {
-            nb = (v.sh_degree + 1) * (v.sh_degree + 1);
-            float3 dc = d_rgb;
-            if (flags & kFlagClampR) dc.x = 0.f;
-            if (flags & kFlagClampG) dc.y = 0.f;
-            if (flags & kFlagClampB) dc.z = 0.f;
-            const float* cp = v.campos;
-            const float3 dv = make_float3(p.x - cp[0], p.y - cp[1], p.z - cp[2]);
-            const float inv_len = 1.0f / sqrtf(dot3(dv, dv));
-            const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
-            float B[16];
-            sh_basis(v.sh_degree, d, B);
-            if (!SH_TO_COLORS)
-                for (int k = 0; k < nb; ++k) {
-                    float* o = k == 0 ? out_lo : out_hi + 3 * k;
-                    o[0] = B[k] * dc.x; o[1] = B[k] * dc.y; o[2] = B[k] * dc.z;
-                }
-            if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
-            if (v.sh_degree > 0) {
-                // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
-                const float4 j0 = jac0, j1 = jac1;
-                const float j22 = jac22;
-                const float3 dd_ = make_float3(dc.x * j0.x + dc.y * j0.w + dc.z * j1.z,
-                                               dc.x * j0.y + dc.y * j1.x + dc.z * j1.w,
-                                               dc.x * j0.z + dc.y * j1.y + dc.z * j22);
-                // through the normalisation d = dv / |dv|
-                const float proj = dot3(d, dd_);
-                d_mean.x += (dd_.x - d.x * proj) * inv_len;
-                d_mean.y += (dd_.y - d.y * proj) * inv_len;
-                d_mean.z += (dd_.z - d.z * proj) * inv_len;
-            }
-        }
-        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { float* o = k == 0 ? out_lo : out_hi + 3 * k; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
-    }
+    if constexpr (!kColourFirst) colour_part();
+    d_mean.x += dm_dir.x; d_mean.y += dm_dir.y; d_mean.z += dm_dir.z;
     if (s.raw) {  // derivatives of the activations: gradients w.r.t. the raw parameters
         if (s.raw & SR_RAW_SCALES) { d_scale.x *= sc_in.x; d_scale.y *= sc_in.y; d_scale.z *= sc_in.z; }   // d exp = exp
         if (s.raw & SR_RAW_OPACITY) d_opac *= opac_in * (1.0f - opac_in);                                   // d sigmoid
@@ -780,17 +803,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
     }
     }  // valid
-    if constexpr (STAGE_SH && !SH_TO_COLORS) {
-        __syncthreads();
-        const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
-#if SR_PREB_DIAG & 2
-        if (s_sh[threadIdx.x].x == 12345.678f)
-#endif
-        {
-        if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
-        else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
-        }
-    }
+    if constexpr (STAGE_SH && !SH_TO_COLORS && !kColourFirst) stage_out_part();
 #if SR_PREB_T3
     {
         // [N,3] tensors: thread t's three floats at floats 3t .. 3t + 2 of the workgroup's block (a 12-byte stride: conflict-free

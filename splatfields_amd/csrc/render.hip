@@ -109,8 +109,12 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #define SR_FWD_PIPE 1   // 1: the trip loop reads the index two trips and the record one trip ahead (software pipeline, two copies of
 #endif                  //    the body so that no register is copied); 0: index -> record -> arithmetic serially in every trip (round 4)
 
-    if (g.total[0] > b.capacity || g.total[1] > b.sorted_up_to) return;  // uniform: see sr_forward / sr_forward_async
+    // (the three scalar loads are requested together and tested with one wait: written as `a > x || b > y` ahead of the tile
+    // lookup they were three dependent memory round trips at the head of every workgroup)
+    const uint32_t total_instances = g.total[0], longest_list = g.total[1];
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
+    asm volatile("" :: "s"(tile));   // (keeps the compiler from sinking this load below the early exit: it is requested with the two above)
+    if ((total_instances > b.capacity) | (longest_list > b.sorted_up_to)) return;  // uniform: see sr_forward / sr_forward_async
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
