@@ -199,13 +199,14 @@ int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, vo
  *                          the SrGrads pointers are the bases of the FULL gradient tensors (rows outside the range are not
  *                          touched).  Any partition of [0, count) into such ranges, in any order, after one
  *                          sr_backward_blend, gives exactly what sr_backward gives (same kernels, same arithmetic per splat).
- * Same buffers and the same `instances` / `instances_rendered` meaning as sr_backward. */
+ * Same buffers and the same `instances` / `instances_rendered` meaning as sr_backward (the per-splat kernel has a variant for
+ * small footprints too: it requests a splat's first gradient slots together with their `reached` bytes). */
 int sr_backward_blend(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
                       long long instances, long long instances_rendered, const void* image,
                       const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch, void* hip_stream);
 int sr_backward_splats(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
-                       long long instances, const void* image, const int* radii, void* scratch, const SrGrads* grads,
-                       int first_splat, int n_splats, void* hip_stream);
+                       long long instances, long long instances_rendered, const void* image, const int* radii, void* scratch,
+                       const SrGrads* grads, int first_splat, int n_splats, void* hip_stream);
 
 /* Pins the backward blend kernel for A/B measurements and for the test that compares the two: 0 = chosen per launch by the
  * footprint (default), 1 = pixel-per-lane kernel, 2 = entry-per-lane kernel.  The initial value comes from the environment

@@ -90,7 +90,7 @@ SYMBOLS = {
                               C.c_void_p]),
     "sr_backward_blend": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sr_backward_splats": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
+    "sr_backward_splats": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(SrGrads), C.c_int, C.c_int, C.c_void_p]),
     "sr_debug_snapshot": (C.c_int, [C.POINTER(SrView), C.POINTER(SrSplats), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sr_set_backward_kernel": (C.c_int, [C.c_int]),

@@ -482,7 +482,10 @@ int backward_impl(int what, const SrView* view, const SrSplats* splats, const vo
         gr.shs = s.shs ? grads->dL_dshs : nullptr;
         gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
         gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
-        { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, first, count, st); }
+        // small footprints (the rule of the blend kernel above; unknown counts as small): the variant that requests a splat's
+        // first gradient slots together with their `reached` bytes
+        const bool small_fp = !(instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N);
+        { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, first, count, small_fp, st); }
         SR_TRY(after_launch(view, st, "preprocess_backward"));
     }
     return 0;
@@ -505,10 +508,10 @@ int sr_backward_blend(const SrView* view, const SrSplats* splats, const void* ge
 }
 
 int sr_backward_splats(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
-                       long long instances, const void* image, const int* radii, void* scratch, const SrGrads* grads,
-                       int first_splat, int n_splats, void* hip_stream) {
-    return backward_impl(2, view, splats, geom, binning, instances, -1, image, radii, nullptr, nullptr, nullptr, scratch, grads,
-                         first_splat, n_splats, hip_stream);
+                       long long instances, long long instances_rendered, const void* image, const int* radii, void* scratch,
+                       const SrGrads* grads, int first_splat, int n_splats, void* hip_stream) {
+    return backward_impl(2, view, splats, geom, binning, instances, instances_rendered, image, radii, nullptr, nullptr, nullptr, scratch,
+                         grads, first_splat, n_splats, hip_stream);
 }
 
 int sr_set_backward_kernel(int which) {

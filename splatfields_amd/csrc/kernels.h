@@ -23,7 +23,8 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 void launch_densification_stats(int N, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii2D,
                                 hipStream_t st);
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
-                                const float* slots, const uint8_t* reached, const GradsK& gr, int first, int count, hipStream_t st);
+                                const float* slots, const uint8_t* reached, const GradsK& gr, int first, int count, bool small_footprint,
+                                hipStream_t st);
 // binning.hip
 // true when the image is small enough for the atomic-free count-matrix bucketing
 inline bool use_count_matrix(const ViewK& v) { return v.gx * v.gy <= kMaxMatrixTiles; }

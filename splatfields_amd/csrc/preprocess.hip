@@ -428,7 +428,7 @@ void launch_mark_visible(int N, const float* means3D, const float* viewmatrix, u
 // SH_TO_COLORS: the splats carry SH, but instead of dL/dsh [N,K,3] the kernel writes the (clamp-masked) colour gradient
 // dL/dcolour [N,3] -- the view-parallel step all-gathers those 12 bytes and rebuilds the SH gradient of all views
 // locally (sh.hip); the gradient through the view direction still goes into dL/dmeans3D here.
-template <bool STAGE_SH, bool SH_TO_COLORS>
+template <bool STAGE_SH, bool SH_TO_COLORS, bool SPEC>
 __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, const SplatsK s, const Geom g,
                                                                 const int* __restrict__ radii,
                                                                 const float* __restrict__ slots,
@@ -496,6 +496,11 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                          //    per CU do not overlap them -- and every round trip taken out of the chain is time.)
     uint32_t reached4 = 0u;
 #if SR_PREB_SPEC
+    // Only for small footprints -- a template parameter, chosen by the host with the rule that picks the backward blend kernel (at
+    // most SR_BWD_WAVE_KERNEL_ABOVE instances per splat on average): with 15 instances per splat (300 k x 0.02) the speculative
+    // form is SLOWER, 0.0787 vs 0.0680 ms (most of a splat's slots are then fetched by the loop below anyway), and a run-time
+    // switch inside one kernel costs the dense case 7 us of its own (0.0749: the speculative registers stay allocated).
+    constexpr bool use_spec = SPEC;
     float4 spec[4][3];
     {
         // branch-free inside the guard: positions beyond the splat's last instance re-request the last one (its line is there)
@@ -507,7 +512,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const uint32_t lasti = min(cnt_in, 4u) - 1u;
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) rb[i] = reached[first_in + min(i, lasti)];
-            if (cnt_in < 32u) {
+            if (use_spec && cnt_in < 32u) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4; ++i) {
                     const uint32_t j = min(i, lasti);
@@ -562,14 +567,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 #if SR_PREB_SPEC
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {   // same order of additions as the loop below: bit-identical sums
-                if (i < cnt_in && ((reached4 >> (8 * i)) & 0xffu) != 0u) {
+                if (use_spec && i < cnt_in && ((reached4 >> (8 * i)) & 0xffu) != 0u) {
                     const float4 a = spec[i][0], b4 = spec[i][1], c4 = spec[i][2];
                     sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
                     sum[4] += b4.x; sum[5] += b4.y; sum[6] += b4.z; sum[7] += b4.w;
                     sum[8] += c4.x; sum[9] += c4.y;
                 }
             }
-            for (uint32_t i = 4; i < cnt_in; ++i) {
+            for (uint32_t i = use_spec ? 4u : 0u; i < cnt_in; ++i) {
 #else
             for (uint32_t i = 0; i < cnt_in; ++i) {
 #endif
@@ -833,16 +838,20 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
-                                const float* slots, const uint8_t* reached, const GradsK& gr, int first, int count, hipStream_t st) {
+                                const float* slots, const uint8_t* reached, const GradsK& gr, int first, int count, bool small_footprint,
+                                hipStream_t st) {
     const int end = first + count < s.N ? first + count : s.N;
     const int nb = (end - first + kBlock - 1) / kBlock;
     if (nb <= 0) return;
     const bool to_colors = s.shs && !gr.shs && gr.colors;
     const bool stage = s.shs && v.sh_coeffs == 16 && gr.shs;  // LDS rows only carry the SH gradient out (coalesced 16-byte stores)
-    if (to_colors && stage) hipLaunchKernelGGL((k_preprocess_backward<true, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
-    else if (to_colors) hipLaunchKernelGGL((k_preprocess_backward<false, true>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
-    else if (stage) hipLaunchKernelGGL((k_preprocess_backward<true, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
-    else hipLaunchKernelGGL((k_preprocess_backward<false, false>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end);
+    const bool spec = small_footprint && SR_PREB_SPEC;
+#define SR_LAUNCH_PB(A, B, C) hipLaunchKernelGGL((k_preprocess_backward<A, B, C>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end)
+    if (to_colors && stage) { if (spec) SR_LAUNCH_PB(true, true, true); else SR_LAUNCH_PB(true, true, false); }
+    else if (to_colors) { if (spec) SR_LAUNCH_PB(false, true, true); else SR_LAUNCH_PB(false, true, false); }
+    else if (stage) { if (spec) SR_LAUNCH_PB(true, false, true); else SR_LAUNCH_PB(true, false, false); }
+    else { if (spec) SR_LAUNCH_PB(false, false, true); else SR_LAUNCH_PB(false, false, false); }
+#undef SR_LAUNCH_PB
 }
 
 }  // namespace sr

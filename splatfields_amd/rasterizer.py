@@ -487,7 +487,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                  _ptr(scratch), stream))
                 for j, (lo, hi) in enumerate(slice_ranges(n, hook.slices)):
                     _lib.check(lib.sr_backward_splats(C.byref(view.struct), C.byref(splats), _ptr(geom), _ptr(binning), ctx.capacity,
-                                                      _ptr(image), _ptr(radii), _ptr(scratch), C.byref(grads), lo, hi - lo, stream))
+                                                      ctx.instances, _ptr(image), _ptr(radii), _ptr(scratch), C.byref(grads), lo, hi - lo, stream))
                     hook.on_slice(j, lo, hi)
         if hook is not None:
             return (None, d_means2D) + (None,) * 12
