@@ -159,6 +159,9 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
         if record:
             vis[0] = float((radii > 0).sum().item())
 
+    import gc
+    gc.collect()
+    gc.disable()            # as for the headline (main): parked from the warm-up to the end of the timed steps
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
@@ -169,6 +172,10 @@ def time_plain_workload(n, width, height, use_sh, mean_scale, sh_degree, steps, 
         step(warmup + i)
     torch.cuda.synchronize()
     ms_per_step = (time.perf_counter() - t0) / steps * 1e3
+    gc.enable()
+    gc.collect()
+    for i in range(24):                        # (the collector's pause left the device idle)
+        step(i)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     stream = torch.cuda.current_stream(dev)
     for i in range(steps):                     # second pass: per-step events (they cost the stream a few microseconds each)
@@ -557,6 +564,15 @@ def main():
     # region after 13 untimed steps takes 538-548 us/step, after 29 steps 530-532, after 61 steps 525 = what every later region
     # takes -- the device needs ~25 ms of this workload (clocks, caches, the allocator's block list) before a 10 ms region
     # measures the steady state.  Nothing is skipped: these are full untimed steps, like the W warm-up steps that follow.
+    # Python's cyclic garbage collector is parked from here to the end of the timed region: a generation-2 pass over the
+    # interpreter's heap (torch is imported: millions of objects) takes milliseconds and comes about once in ~200 steps of this
+    # loop -- one of them inside a 10 ms region is a 15-40 % error (seen in round 5: 0.584 ms wall mean beside a 0.503 median).
+    # Collected HERE, in front of the untimed steps: a pause of the host between the warm-up and the timed region lets the
+    # device fall idle, and the first steps behind ~50 ms of idleness run 10-25 % slower (measured: 0.572-0.581 instead of 0.51).
+    import gc
+    gc.collect()
+    if os.environ.get("BENCH_KEEP_GC") != "1":
+        gc.disable()
     for _ in range(PRE_CYCLES):
         for i in range(len(cams)):
             one_step(i)
@@ -575,9 +591,14 @@ def main():
         one_step(args.warmup + i)
     fence()
     t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    gc.enable()
+    gc.collect()   # (now, not as a surprise in the middle of the next pass)
     host_sync = rz.host_sync_counters()
     # second pass over the same K steps, each bracketed by HIP events on the launch stream (median / min / max of a step) and,
     # for N > 1, with the exchange instrumentation on
+    for _ in range(3):   # the collector's pause above left the device idle: three untimed cycles before the events pass
+        for i in range(len(cams)):
+            one_step(i)
     ExchangeStats.reset(world > 1 or args.force_dp_path)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     stream = torch.cuda.current_stream(dev)
