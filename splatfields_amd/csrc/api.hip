@@ -414,10 +414,16 @@ int sr_ticket_wait(void* ticket, long long* instances_out, long long* longest_li
     bool waited = false;
     const int rc = status_block_wait(*t, &waited);
     if (waited) g_counters[2].fetch_add(1, std::memory_order_relaxed);
+    if (rc) {
+        // The figures never arrived (failed launch, lost device): the block is NOT handed out again -- a k_scan_small that runs
+        // late after all would write into a block that belongs to another forward by then -- and the outputs stay untouched.
+        // 64 bytes of pinned memory are leaked per failed forward; the process is about to report a device error anyway.
+        return rc;
+    }
     if (instances_out) *instances_out = (long long)t->pinned[0];
     if (longest_list_out) *longest_list_out = (long long)t->pinned[1];
     ticket_recycle(t);
-    return rc;
+    return 0;
 }
 
 long long sr_last_longest_list(void) { return g_last_longest; }

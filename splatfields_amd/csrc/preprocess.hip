@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
 #endif                   //    consecutive 16-byte pieces of the workgroup's contiguous 16 KB (whole lines per wave-instruction);
                          //    0: every thread stores its own four quarters (16-byte pieces at a 64-byte stride: the L2 has to
                          //    assemble every line from four partial writes; rounds 1-4)
-    constexpr int kRecRow = kBlock + 1;   // float4 per quarter row: + 1 keeps the transposed reads off each other's banks
+    // float4 per quarter row.  Lane l of the transposed read takes quarter l & 3 of record l >> 2: eight consecutive lanes -- one
+    // 128-byte LDS pass -- hit the 16-byte bank groups (q R + r) mod 8, q = 0..3, r = 0..1, which are all different iff
+    // R = 2 (mod 8).  (Round 5 padded by 1: lanes 1..3 of a record shared their groups with lanes 4..6 of the next one.)
+    constexpr int kRecRow = kBlock + 2;
     constexpr int kRecF4 = SR_PRE_REC_T ? 4 * kRecRow : 1;
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : kRecF4];   // SH staging first; the records' transpose afterwards
     static_assert(!STAGE_SH || kBlock * kShRowF4 >= kRecF4, "the record transpose reuses the SH staging area");
@@ -256,16 +259,42 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                         const float inv_len = 1.0f / sqrtf(dot3(d, d));
                         d.x *= inv_len; d.y *= inv_len; d.z *= inv_len;
                         float B[16];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) B[k] = 0.f;   // bands above the active degree contribute nothing
                         sh_basis(v.sh_degree, d, B);
-                        // float j = 3k + c of this splat's coefficients: sh_lo[j] for the dc triple, sh_hi[j] for the rest
-                        // (the same row unless the two-tensor input is staged as two spans)
-                        float *sh_lo, *sh_hi;
-                        if (STAGE_SH) sh_row_pointers(s_sh, s.shs_rest != nullptr, threadIdx.x, sh_lo, sh_hi);
-                        else sh_lo = sh_hi = const_cast<float*>(s.shs) + (size_t)idx * v.sh_coeffs * 3;
                         const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
-                        rgb = make_float3(sh_lo[0] * B[0], sh_lo[1] * B[0], sh_lo[2] * B[0]);
-                        for (int k = 1; k < nb; ++k) {
-                            rgb.x += B[k] * sh_hi[3 * k]; rgb.y += B[k] * sh_hi[3 * k + 1]; rgb.z += B[k] * sh_hi[3 * k + 2];
+                        // This splat's coefficients into registers ONCE (float j = 3k + c; zero beyond the active bands).
+                        // Staged, one source tensor: the thread's LDS row is 13 float4, read as twelve 16-byte pieces -- the odd
+                        // row length makes those conflict-free.  (Rounds 1-5 read the row float by float, ~90 ds_read_b32 per
+                        // thread at a stride of 52 floats = 20 banks: four lanes on every bank, 9.7 M bank-conflict cycles per
+                        // launch -- SQ_LDS_BANK_CONFLICT, profiles/r05_v3_pmc.json -- for 1.6 M LDS instructions.)
+                        float shc[48];
+                        if (STAGE_SH && !s.shs_rest) {
+                            const float4* row = s_sh + kShRowF4 * (int)threadIdx.x;
+#pragma unroll
+                            for (int it = 0; it < 12; ++it) {
+                                const float4 t4 = row[it];
+                                shc[4 * it] = t4.x; shc[4 * it + 1] = t4.y; shc[4 * it + 2] = t4.z; shc[4 * it + 3] = t4.w;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) if (k >= nb) { shc[3 * k] = 0.f; shc[3 * k + 1] = 0.f; shc[3 * k + 2] = 0.f; }
+                        } else {
+                            // two-tensor staging (odd strides of 3 and 45 floats: conflict-free 4-byte reads) or straight from memory:
+                            // sh_lo[j] for the dc triple, sh_hi[j] for the rest
+                            float *sh_lo, *sh_hi;
+                            if (STAGE_SH) sh_row_pointers(s_sh, true, threadIdx.x, sh_lo, sh_hi);
+                            else sh_lo = sh_hi = const_cast<float*>(s.shs) + (size_t)idx * v.sh_coeffs * 3;
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                const float* src = k == 0 ? sh_lo : sh_hi + 3 * k;
+                                const bool on = k < nb;
+                                shc[3 * k] = on ? src[0] : 0.f; shc[3 * k + 1] = on ? src[1] : 0.f; shc[3 * k + 2] = on ? src[2] : 0.f;
+                            }
+                        }
+                        rgb = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            rgb.x = fmaf(B[k], shc[3 * k], rgb.x); rgb.y = fmaf(B[k], shc[3 * k + 1], rgb.y); rgb.z = fmaf(B[k], shc[3 * k + 2], rgb.z);
                         }
                         if (v.sh_degree > 0 && !(s.raw & SR_FORWARD_ONLY)) {
                             // d colour / d direction while the coefficients are at hand (36 bytes per splat instead of the
@@ -275,7 +304,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
                             for (int ch = 0; ch < 3; ++ch) {
                                 float gk[16];
 #pragma unroll
-                                for (int k = 0; k < 16; ++k) gk[k] = k < nb ? (k == 0 ? sh_lo[ch] : sh_hi[3 * k + ch]) : 0.f;
+                                for (int k = 0; k < 16; ++k) gk[k] = shc[3 * k + ch];
                                 const float3 j = sh_dir_gradient(v.sh_degree, d, gk);
                                 jac[3 * ch] = j.x; jac[3 * ch + 1] = j.y; jac[3 * ch + 2] = j.z;
                             }
@@ -616,11 +645,24 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             const float3 d = make_float3(dv.x * inv_len, dv.y * inv_len, dv.z * inv_len);
             float B[16];
             sh_basis(v.sh_degree, d, B);
-            if (!SH_TO_COLORS)
+            if (!SH_TO_COLORS && !(STAGE_SH && !gr.shs_rest))
                 for (int k = 0; k < nb; ++k) {
                     float* o = k == 0 ? out_lo : out_hi + 3 * k;
                     o[0] = B[k] * dc.x; o[1] = B[k] * dc.y; o[2] = B[k] * dc.z;
                 }
+            if (!SH_TO_COLORS && STAGE_SH && !gr.shs_rest) {
+                // the thread's padded LDS row (13 float4) written as twelve 16-byte pieces: conflict-free, where the 48 float
+                // stores of rounds 1-5 (stride 52 floats = 20 banks) put four lanes on every bank
+                float g48[48];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float bk = k < nb ? B[k] : 0.f;
+                    g48[3 * k] = bk * dc.x; g48[3 * k + 1] = bk * dc.y; g48[3 * k + 2] = bk * dc.z;
+                }
+                float4* row = s_sh + kShRowF4 * (int)threadIdx.x;
+#pragma unroll
+                for (int it = 0; it < 12; ++it) row[it] = make_float4(g48[4 * it], g48[4 * it + 1], g48[4 * it + 2], g48[4 * it + 3]);
+            }
             if (SH_TO_COLORS) d_rgb = dc;  // what leaves is the masked colour gradient
             if (v.sh_degree > 0) {
                 // dL/d(unit direction) = sum_c dL/dcolour_c * d colour_c / d direction (Jacobian stored by the forward)
@@ -634,7 +676,17 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                 dm_dir = make_float3((dd_.x - d.x * proj) * inv_len, (dd_.y - d.y * proj) * inv_len, (dd_.z - d.z * proj) * inv_len);
             }
         }
-        if (!SH_TO_COLORS) for (int k = nb; k < K; ++k) { float* o = k == 0 ? out_lo : out_hi + 3 * k; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
+        if (!SH_TO_COLORS) {
+            if (STAGE_SH && !gr.shs_rest) {
+                if (!visible) {   // (a visible splat's row was written whole above)
+                    float4* row = s_sh + kShRowF4 * (int)threadIdx.x;
+#pragma unroll
+                    for (int it = 0; it < 12; ++it) row[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                for (int k = nb; k < K; ++k) { float* o = k == 0 ? out_lo : out_hi + 3 * k; o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
+            }
+        }
     }
     };
     auto stage_out_part = [&]() {

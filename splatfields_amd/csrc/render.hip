@@ -108,13 +108,31 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
 #ifndef SR_FWD_PIPE
 #define SR_FWD_PIPE 1   // 1: the trip loop reads the index two trips and the record one trip ahead (software pipeline, two copies of
 #endif                  //    the body so that no register is copied); 0: index -> record -> arithmetic serially in every trip (round 4)
+    // the pipelined walk fetches a record by an index byte it has not masked yet (a stale byte of s_idx): any byte must be a slot
+    static_assert(!SR_FWD_PIPE || !SR_FWD_QUADS || kB == 256, "the pipelined walk indexes the staging area with unmasked bytes: 256 slots");
 
     // (the three scalar loads are requested together and tested with one wait: written as `a > x || b > y` ahead of the tile
     // lookup they were three dependent memory round trips at the head of every workgroup)
     const uint32_t total_instances = g.total[0], longest_list = g.total[1];
     const int tile = (int)g.tile_order[blockIdx.x];  // longest lists first
     asm volatile("" :: "s"(tile));   // (keeps the compiler from sinking this load below the early exit: it is requested with the two above)
-    if ((total_instances > b.capacity) | (longest_list > b.sorted_up_to)) return;  // uniform: see sr_forward / sr_forward_async
+    if ((total_instances > b.capacity) | (longest_list > b.sorted_up_to)) {   // uniform: see sr_forward / sr_forward_async
+        // The launch was made on a promise (sr_forward_async: capacity / sort classes of the camera's last render) that did not
+        // hold: the lists of this view were never built.  The view has NO result, and it must not be possible to mistake what
+        // the output buffers happen to hold for one: every workgroup fills its tile with NaN (by grid position: the launch
+        // order table is not needed), so a loss computed from this image is NaN until the caller, told by its ticket
+        // (RasterizerOverflow), renders again.
+        const int t = (int)blockIdx.x, lx = (int)threadIdx.x & 15, ly = (int)threadIdx.x >> 4;
+        const int qx = (t % v.gx) * kTile + lx, qy = (t / v.gx) * kTile + ly;
+        if (qx < v.W && qy < v.H) {
+            const size_t hw = (size_t)v.H * v.W, pix = (size_t)qy * v.W + qx;
+            const float nan = __builtin_nanf("");
+            out_color[pix] = nan; out_color[hw + pix] = nan; out_color[2 * hw + pix] = nan;
+            out_depth[pix] = nan;
+            if (out_alpha) out_alpha[pix] = nan;
+        }
+        return;
+    }
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;

@@ -12,7 +12,21 @@ import math
 
 import torch
 
+from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _redeemed(render_fn):
+    """`render_fn()`'s outputs with every asynchronously launched forward of this host thread checked (rasterizer.py:
+    sr_forward_async; only when the caller has switched that on): a forward whose capacity promise did not hold has no result
+    and is rendered again -- the estimates are corrected by then."""
+    out = render_fn()
+    try:
+        _rz.resolve_pending()
+    except _rz.RasterizerOverflow:
+        out = render_fn()
+        _rz.resolve_pending()
+    return out
 
 
 def render(viewpoint_camera, gaussian_dict: dict, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
@@ -45,9 +59,14 @@ def render(viewpoint_camera, gaussian_dict: dict, pipe, bg_color: torch.Tensor, 
             campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
 
     rasterizer = GaussianRasterizer(raster_settings=settings(bg_color))
-    rendered_image, radii, depth, alpha = rasterizer.forward_ex(
-        means3D=means3D, means2D=screenspace_points, shs=gaussian_features, colors_precomp=gaussian_rgb,
-        opacities=gaussian_opacity, scales=gaussian_scales, rotations=gaussian_rotations, cov3D_precomp=None)
+    kw = dict(means3D=means3D, means2D=screenspace_points, shs=gaussian_features, colors_precomp=gaussian_rgb,
+              opacities=gaussian_opacity, scales=gaussian_scales, rotations=gaussian_rotations, cov3D_precomp=None)
+    if two_pass:   # the reference's literal calls: the three-output `forward` (:94-102), then the mask rasterizer (:104-115)
+        fwd = lambda: rasterizer(**kw) + (None,)
+    else:
+        fwd = lambda: rasterizer.forward_ex(**kw)
+    # pipe.debug: nothing leaves this function unchecked (with SPLATRASTER_ASYNC=1 a forward may have been launched on a promise)
+    rendered_image, radii, depth, alpha = _redeemed(fwd) if getattr(pipe, "debug", False) else fwd()
     opacity_image = None
     if return_opacity:
         if two_pass:
@@ -89,8 +108,9 @@ def render_model(viewpoint_camera, gaussians, pipe, bg_color: torch.Tensor, scal
         kw = dict(shs=dc, shs_rest=rest)
     else:  # other SH widths: the concatenated tensor, as the accessor builds it
         kw = dict(shs=torch.cat((dc, rest), dim=1))
-    rendered_image, radii, depth, alpha = GaussianRasterizer(raster_settings=rs).forward_raw(
+    fwd = lambda: GaussianRasterizer(raster_settings=rs).forward_raw(
         means3D=means3D, means2D=screenspace_points, opacity_logits=gaussians._opacity, log_scales=log_scales,
         quaternions=gaussians._rotation, **kw)
+    rendered_image, radii, depth, alpha = _redeemed(fwd) if getattr(pipe, "debug", False) else fwd()
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "opacity": alpha if return_opacity else None, "depth": depth}

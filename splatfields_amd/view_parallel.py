@@ -109,12 +109,13 @@ def _checked(render_fn: Callable):
     back-propagates: a forward whose capacity guess did not hold is re-rendered (the estimates are corrected by then), so the
     step functions never see RasterizerOverflow in the middle of an autograd pass -- and a rank never re-issues collectives."""
     from . import rasterizer as rz
-    out = render_fn()
-    try:
-        rz.resolve_pending()
-    except rz.RasterizerOverflow:
+    with rz.async_forward():   # the tickets are redeemed right here: this is the caller the asynchronous launch is for
         out = render_fn()
-        rz.resolve_pending()
+        try:
+            rz.resolve_pending()
+        except rz.RasterizerOverflow:
+            out = render_fn()
+            rz.resolve_pending()
     return out
 
 

@@ -113,3 +113,51 @@ def record_observed(tag: str, figures: dict) -> None:
             f.write(line + "\n")
     except OSError:
         pass
+
+
+XY_ULPS = 4.0   # float ulps of rounding assumed in a splat's stored screen-space centre (oracle/raster_ref.c `cond_bound`): HIP's
+                # ((x_ndc + 1) W - 1) / 2 in fp32 is within ~2.3 ulp of the exact value (tools/parity_fullsize.py, 32 comparisons),
+                # the fp32 oracle's own evaluation within 2
+
+
+def assert_parity_explained(out: dict, g: dict, sp: dict, st, grads, *, use_sh: bool, tag: str, precisions=("fp64", "fp32"),
+                            threads=None) -> dict:
+    """The large-scene parity statement: against the C oracle in double AND in float, with the
+    oracle's own account of what may legitimately differ between two fp32 evaluations,
+      (a) every pixel whose threshold decisions are clear of their thresholds (not `fragile`) is within 1e-4 relative
+          (to max(|ref|, 1e-3): the north star's bound) plus the oracle's first-order bound for XY_ULPS ulps of rounding in the
+          splats' float screen-space centres -- a term that matters only where the rim of one or two faint splats is all a pixel
+          shows -- and a fragile pixel is within one blended pair (2e-2 absolute);
+      (b) every gradient element beyond 1e-3 of its tensor's maximum belongs to a splat that is blended into a fragile pixel
+          (`splat_flag`), and no element anywhere is beyond 5e-2;
+      (c) radii are equal except where 3 sqrt(lambda) is within rounding of an integer.
+    `unexplained` -- anything outside (a)-(c) -- must be 0."""
+    import os
+    from oracle import c_oracle, parity as P
+    threads = threads or min(128, os.cpu_count() or 8)
+    figs = {}
+    for prec in precisions:
+        ref, rg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=threads,
+                                        precision=prec, fragile=True, xy_ulps=XY_ULPS)
+        fig = P.compare_flagged(out, g, ref, rg)
+        figs[prec] = fig
+        record_observed(f"{tag} vs {prec}", {
+            "unexplained": fig["unexplained"], "radii": fig["radii"], "image_robust_max_rel": fig["image_robust_max_rel"],
+            "image_robust_above_1e-4": fig["image_robust_above_1e-4"], "conditioning_limited": fig["image_conditioning_limited"],
+            "max_err_over_allowance": max(v.get("max_err_over_allowance", 0.0) for v in fig["images"].values()),
+            "fragile_share": fig["images"]["color"]["fragile_share"],
+            "fragile_max_abs": max(v["fragile_max_abs"] for v in fig["images"].values()),
+            "flagged_splat_share": fig["flagged_splat_share"], "grad_max": max(v["max_rel_to_tensor_max"] for v in fig["gradients"].values()),
+            "grad_max_unflagged": fig["gradient_max_unflagged"]})
+        assert fig["radii"]["unexplained"] == 0, (tag, prec, fig["radii"])
+        for k, v in fig["images"].items():
+            assert v["unexplained"] == 0, (tag, prec, k, v)
+            assert v["median_rel"] < 1e-5, (tag, prec, k, v)
+            assert v["fragile_max_abs"] <= 2e-2 * max(1.0, float(ref[k].abs().max())), (tag, prec, k, v)
+        assert fig["images"]["color"]["fragile_share"] < 0.2, (tag, prec, fig["images"]["color"]["fragile_share"])
+        for k, v in fig["gradients"].items():
+            assert v["unexplained"] == 0, (tag, prec, k, v)
+            assert v["max_rel_to_tensor_max"] <= 5e-2, (tag, prec, k, v)
+            assert v["median_rel_to_tensor_max"] <= 1e-6, (tag, prec, k, v)
+        assert fig["unexplained"] == 0, (tag, prec)
+    return figs

@@ -205,3 +205,152 @@ def test_dropped_forwards_hand_their_tickets_back(scene):
         del out
     torch.cuda.synchronize()
     assert rz.host_sync_counters()["tickets_created"] - before <= 4
+
+
+def test_plain_facade_waits_by_default_and_step_functions_do_not(scene):
+    """an unmodified training loop never redeems a ticket before it reads the image (the reference even
+    renders with gradients enabled and never back-propagates, train.py:379-387), so the plain facade waits in every forward
+    unless the caller opts in; the step functions, which redeem and re-render, launch asynchronously on their own."""
+    from splatfields_amd import rasterizer as rz
+    from splatfields_amd.view_parallel import sh_gather_step
+    sp, cams, bg, grads = scene
+    prev = rz.set_async_forward(None)                             # the default policy
+    try:
+        assert not rz.async_forward_enabled()
+        _step(sp, cams, bg, grads)                                # cameras known
+        rz.host_sync_counters(reset=True)
+        _step(sp, cams, bg, grads)
+        c = rz.host_sync_counters()
+        assert c["async_forwards"] == 0 and c["forward_host_waits"] == len(cams), c
+        with rz.async_forward():                                  # a caller that redeems the tickets itself
+            assert rz.async_forward_enabled()
+            rz.host_sync_counters(reset=True)
+            p = _leaves(sp)
+            (col, r, d, a), m2 = _forward(p, cams[0], bg)
+            rz.resolve_pending()
+            assert rz.host_sync_counters()["async_forwards"] == 1
+        assert not rz.async_forward_enabled()
+        gi, gd, ga = grads
+        p = _leaves(sp)
+        rz.host_sync_counters(reset=True)
+        sh_gather_step(p, cams, bg, 3, lambda vi, c_, d_, a_: torch.autograd.backward((c_, d_, a_), (gi, gd, ga)), rank=0, world=1)
+        c = rz.host_sync_counters()
+        assert c["async_forwards"] == len(cams) and c["forward_host_waits"] == 0, c
+        rz.set_async_forward(False)                               # an explicit "off" also binds the step functions
+        rz.host_sync_counters(reset=True)
+        sh_gather_step(_leaves(sp), cams, bg, 3, lambda vi, c_, d_, a_: torch.autograd.backward((c_, d_, a_), (gi, gd, ga)), rank=0, world=1)
+        assert rz.host_sync_counters()["async_forwards"] == 0
+    finally:
+        rz.set_async_forward(prev)
+
+
+def test_a_stale_promise_cannot_be_consumed_silently(scene):
+    """a loop that reads loss.item() (or saves the image) between a forward launched on a stale
+    promise and its backward must not see a plausible number: the forward blend's overflow exit fills colour, depth and alpha
+    with NaN on the device, and the ticket raises RasterizerOverflow."""
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    cam = cams[2]
+    _step(sp, [cam], bg, grads)
+    big = dict(sp, scales=sp["scales"] * 12.0)
+    pack = rz._ViewPack.get(_settings(cam, bg), sp["means3D"].device, 16)
+    inst_small = pack.seen[N][0]
+    key = (sp["means3D"].device.index, N, H, W)
+    rz._CAPACITY[key] = rz._round_capacity(inst_small)            # only the small cloud has ever been seen
+    p = _leaves(big)
+    (c, r, d, a), m2 = _forward(p, cam, bg)
+    loss = (c * grads[0]).sum() + (d * grads[1]).sum() + (a * grads[2]).sum()
+    assert math.isnan(loss.item())                                # what a logging line between forward and backward prints
+    assert torch.isnan(c).all() and torch.isnan(d).all() and torch.isnan(a).all()
+    with pytest.raises(rz.RasterizerOverflow, match="no result"):
+        rz.resolve_pending()
+    with pytest.raises(rz.RasterizerOverflow):                    # and the backward still refuses
+        loss.backward()
+    assert all(v.grad is None for v in p.values())
+    # render(): with pipe.debug nothing unchecked leaves the function -- the stale forward is rendered again inside
+    from types import SimpleNamespace
+    from splatfields_amd.render import render
+    rz._CAPACITY[key] = rz._round_capacity(inst_small)
+    pack.seen[N] = (inst_small, pack.seen[N][1])
+    gd_ = {"means3D": big["means3D"], "active_sh_degree": 3, "gaussian_opacity": big["opacities"], "gaussian_scales": big["scales"],
+           "gaussian_rotations": big["rotations"], "gaussian_features": big["shs"]}
+    res = render(cam, gd_, SimpleNamespace(debug=True), bg)
+    assert torch.isfinite(res["render"]).all() and torch.isfinite(res["opacity"]).all()
+
+
+def test_a_fresh_background_tensor_per_call_keeps_the_camera_known(scene):
+    """the reference builds `bg_color*0.0` per call (gaussian_renderer/__init__.py:81): the camera is the same camera"""
+    from splatfields_amd import rasterizer as rz
+    sp, cams, bg, grads = scene
+    _step(sp, cams[:1], bg, grads)
+    rz.host_sync_counters(reset=True)
+    p = _leaves(sp)
+    (c, r, d, a), m2 = _forward(p, cams[0], bg * 0.0)             # a new tensor object
+    rz.resolve_pending()
+    assert rz.host_sync_counters()["async_forwards"] == 1
+    assert torch.allclose(a, _forward(_leaves(sp), cams[0], bg)[0][3])   # alpha does not depend on the background
+
+
+def test_the_reference_mask_pass_is_served_from_the_first_pass(hip_device):
+    """the UNMODIFIED reference render() (gaussian_renderer/__init__.py:94-115) calls the rasterizer
+    a second time with white colours on a black background.  The facade answers that call with the first pass's alpha output
+    -- same values, same gradients as two full passes, no second rasterization and no host wait."""
+    from types import SimpleNamespace
+    from splatfields_amd import rasterizer as rz
+    from splatfields_amd.render import render
+    dev = hip_device
+    sp = make_splats(N, seed=3, device=dev, mean_scale=0.03)
+    cam = make_camera(1, W, H, device=dev)
+    bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
+    gi, gd, ga = make_upstream_grads(H, W, device=dev)
+    pipe = SimpleNamespace(debug=False)
+
+    def run(shortcut: bool):
+        prev = rz.set_mask_shortcut(shortcut)
+        try:
+            p = _leaves(sp)
+            gdict = {"means3D": p["means3D"], "active_sh_degree": 3, "gaussian_opacity": p["opacities"], "gaussian_scales": p["scales"],
+                     "gaussian_rotations": p["rotations"], "gaussian_features": p["shs"]}
+            res = render(cam, gdict, pipe, bg, two_pass=True)      # the literal call pattern of the reference
+            loss = (res["render"] * gi).sum() + (res["depth"] * gd).sum() + (res["opacity"] * ga).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return res, {k: v.grad.clone() for k, v in p.items()}, res["viewspace_points"].grad.clone()
+        finally:
+            rz.set_mask_shortcut(prev)
+
+    ref, gref, m2ref = run(False)                                  # two full rasterizations
+    before = rz.MASK_CALLS_SERVED
+    rz.host_sync_counters(reset=True)
+    got, g, m2 = run(True)
+    c = rz.host_sync_counters()
+    assert rz.MASK_CALLS_SERVED == before + 1
+    assert c["forward_host_waits"] + c["async_forwards"] == 1, c   # ONE rasterization, and the mask pass waited for nothing
+    assert got["opacity"].shape == ref["opacity"].shape == (1, H, W)
+    assert torch.allclose(got["opacity"], ref["opacity"], rtol=0, atol=1e-6)
+    assert torch.equal(got["render"], ref["render"]) and torch.equal(got["depth"], ref["depth"])
+    for k in NAMES:
+        scale = gref[k].abs().max().item()
+        assert torch.allclose(g[k], gref[k], rtol=0, atol=2e-5 * scale), (k, (g[k] - gref[k]).abs().max().item() / scale)
+    assert torch.allclose(m2, m2ref, rtol=0, atol=2e-5 * m2ref.abs().max().item())
+    # a call that only LOOKS like the mask pass (other colours) is answered with NaN, never with a wrong mask, and switches
+    # the shortcut off for the process once its verdict has arrived
+    import warnings
+    from diff_gaussian_rasterization import GaussianRasterizer
+    prev = rz.set_mask_shortcut(True)
+    try:
+        p = _leaves(sp)
+        m2_ = torch.zeros_like(p["means3D"], requires_grad=True)
+        kw = dict(means3D=p["means3D"], means2D=m2_, opacities=p["opacities"], scales=p["scales"], rotations=p["rotations"])
+        GaussianRasterizer(_settings(cam, bg))(shs=p["shs"], **kw)
+        fake = GaussianRasterizer(_settings(cam, bg * 0.0))(colors_precomp=torch.full((N, 3), 0.5, device=dev), **kw)[0]
+        assert torch.isnan(fake).all()
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            GaussianRasterizer(_settings(cam, bg))(shs=p["shs"], **kw)
+            real = GaussianRasterizer(_settings(cam, bg * 0.0))(colors_precomp=torch.full((N, 3), 0.5, device=dev), **kw)[0]
+        assert any("mask pass" in str(x.message) for x in w)
+        assert not rz._MASK_SHORTCUT and torch.isfinite(real).all()   # rasterized in full from now on
+    finally:
+        rz.set_mask_shortcut(prev)

@@ -10,45 +10,18 @@ import torch
 from oracle import c_oracle
 from oracle import torch_oracle as O
 from splatfields_amd.synthetic import make_camera, make_splats, make_upstream_grads
-from tests.helpers import grad_error, record_observed, run_hip
+from tests.helpers import grad_error, run_hip
 
 pytestmark = pytest.mark.gpu
 
 
-def compare_with_c_oracle(sp, st, grads, dev, use_sh, grad_tol=2e-3, tag="config"):
+def compare_with_c_oracle(sp, st, grads, dev, use_sh, tag="config"):
+    """images, radii and all gradients of one view against the C oracle in double and in float: nothing unexplained
+    (tests/helpers.py: assert_parity_explained -- non-fragile pixels within 1e-4, gradient outliers only on splats blended into a
+    threshold-fragile pixel)"""
+    from tests.helpers import assert_parity_explained
     out, g = run_hip(sp, st, grads, dev, use_sh=use_sh)
-    ref, cg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=16)
-    from oracle import parity as P
-    fig = P.compare(out, g, ref, cg)
-    record_observed(tag, {"image_share_above_1e-4": fig["image_share_above_1e-4"],
-                          "image_max_abs": max(v["max_abs"] for v in fig["images"].values()),
-                          "image_median_rel": max(v["median_rel"] for v in fig["images"].values()),
-                          "grad_max": fig["gradient_max_rel_to_tensor_max"],
-                          "grad_share_above_1e-3": max(v["share_above_1e-3"] for v in fig["gradients"].values()),
-                          "grad_share_above_tol": max(float(((g[k].double() - cg[k].double()).abs() > grad_tol * cg[k].double().abs().max()).double().mean())
-                                                      for k in cg),
-                          "grad_l2_rel": max(float((g[k].double() - cg[k].double()).norm() / cg[k].double().norm()) for k in cg)})
-    # ceil(3 sqrt(lambda)) of two fp32 implementations may differ by one where the argument is within an ulp of an integer
-    dr = (out["radii"].long() - ref["radii"].long()).abs()
-    assert int((dr > 0).sum()) <= max(2, int(1e-5 * dr.numel())) and int(dr.max()) <= 1
-    # Bounds = at most ~10 x what these comparisons observe on MI355X (round 5, gpurun_out/parity_observed.jsonl, 15 views of
-    # configs[1], [2], [4]): median relative error <= 9.1e-7, share of pixels above 1e-4 (threshold flips between two fp32
-    # evaluations) <= 1.3e-4, largest absolute error 1.4e-2 (depth image); gradients: largest element error 4.7e-3 of the
-    # tensor's maximum, L2 error <= 5.4e-4, share of elements beyond 2e-3 <= 1e-5.  (Rounds 1-4: 2e-5 / 2e-3 / 5e-2.)
-    for k in ("color", "depth", "alpha"):
-        a, b = out[k].double(), ref[k].double()
-        rel = (a - b).abs() / b.abs().clamp_min(1e-3)
-        assert rel.median().item() < 1e-5, k
-        assert (rel > 1e-4).float().mean().item() < 1e-3, k  # two fp32 implementations: a few threshold flips
-        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), k
-    for k in cg:
-        a, b = g[k].double(), cg[k].double()
-        # a single flipped threshold decision moves one splat's gradient by a discrete amount, so the max norm is
-        # bounded loosely and the bulk agreement is measured in L2 and by the fraction of outliers
-        scale = b.abs().max().item()
-        assert ((a - b).norm() / b.norm()).item() <= 1e-3, (k, ((a - b).norm() / b.norm()).item())
-        assert ((a - b).abs() > grad_tol * scale).float().mean().item() <= 1e-4, k
-        assert grad_error(g[k], cg[k]) <= 2.5e-2, (k, grad_error(g[k], cg[k]))
+    assert_parity_explained(out, g, sp, st, grads, use_sh=use_sh, tag=tag)
     return out
 
 
@@ -234,5 +207,15 @@ def test_two_tensor_sh_input_equals_concatenated(hip_device, n):
             c, r, d, a = GaussianRasterizer(rs_d).forward_ex(**kw)
             torch.autograd.backward((c, d, a), (gi, gd, ga))
             outs.append((c.detach(), d.detach(), a.detach(), r, dc.grad, rest.grad, geo["means3D"].grad, geo["opacities"].grad))
-        for x, y in zip(*outs):
-            assert torch.equal(x, y)
+        names = ("color", "depth", "alpha", "radii", "d_dc", "d_rest", "d_means3D", "d_opacities")
+        for name, x, y in zip(names, *outs):
+            if deg >= 2 or name == "radii":
+                # both inputs run the SAME kernel instantiation (staged SH block): bit-identical
+                assert torch.equal(x, y), (deg, name)
+            else:
+                # below degree 2 the concatenated tensor takes the unstaged instantiation (it reads <= 48 of a splat's 192 bytes)
+                # and the two-tensor input the staged one: the same statements compiled twice, which the compiler may contract
+                # into fused multiply-adds differently -- equal to fp32 rounding, not bit for bit
+                scale = max(float(y.abs().max()), 1e-30)
+                assert torch.allclose(x, y, rtol=0, atol=1e-4 * scale), (deg, name, float((x - y).abs().max()) / scale)
+                assert ((x - y).abs() > 2e-6 * scale).float().mean().item() < 1e-3, (deg, name)
