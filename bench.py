@@ -517,10 +517,11 @@ def headline_parity(view, n, height, width, use_sh, sh_degree, mean_scale, dev) 
     total_unexplained = 0
     for prec in ("fp32", "fp64"):
         ref, rg, _ = c_oracle.rasterize(sp_cpu, st, use_sh=use_sh, g_img=gcpu[0], g_depth=gcpu[1], g_alpha=gcpu[2],
-                                        threads=min(128, os.cpu_count() or 8), precision=prec, fragile=True, xy_ulps=4.0)
+                                        threads=min(128, os.cpu_count() or 8), precision=prec, fragile=True,
+                                        xy_ulps={"fp64": 4.0, "fp32": 6.0}[prec])   # tests/helpers.py: XY_ULPS
         if prec == "fp32":   # the round-5 figures (no account of fragile pixels), for continuity
             res.update(P.compare(out, g, ref, rg))
-        fig = P.compare_flagged(out, g, ref, rg)
+        fig = P.compare_flagged(out, g, ref, rg, oracle_precision=prec)
         total_unexplained += fig["unexplained"]
         res["explained"][prec] = {
             "unexplained": fig["unexplained"], "radii": fig["radii"],
@@ -535,9 +536,9 @@ def headline_parity(view, n, height, width, use_sh, sh_degree, mean_scale, dev) 
     res["unexplained"] = total_unexplained
     res["against"] = ("oracle/raster_ref.c, explicit backward, in float (libraster_ref.so: the arithmetic timed as cpu_baseline) and in "
                       "double (libraster_ref64.so): same inputs, view %d, whole image" % view)
-    res["tolerance"] = ("north star: <= 1e-4 max relative image error (relative to max(|ref|, 1e-3)) on pixels whose threshold decisions "
-                        "do not sit within the fp32 margin of their threshold, plus the oracle's first-order bound for 4 float ulps of "
-                        "rounding in the splats' stored screen-space centres; gradient elements beyond 1e-3 of the tensor's maximum only "
+    res["tolerance"] = ("north star: <= 1e-4 max relative image error (relative to max(|ref|, 1e-3); 2e-4 against the oracle in float, itself an fp32 evaluation) on pixels whose threshold decisions "
+                        "do not sit within the fp32 margin of their threshold, plus the oracle's first-order bound for 4 float ulps (6 against "
+                        "the oracle in float, where both sides round) of rounding in the splats' stored screen-space centres; gradient elements beyond 1e-3 of the tensor's maximum only "
                         "on splats blended into a fragile pixel; `unexplained` counts everything outside that, against the oracle in "
                         "float and in double")
     return res

@@ -46,14 +46,17 @@ def compare(out: dict, grads: dict, ref_out: dict, ref_grads: dict) -> dict:
     return res
 
 
-def image_figures_robust(hip: torch.Tensor, ref: torch.Tensor, fragile: torch.Tensor, bound: torch.Tensor = None) -> dict:
+def image_figures_robust(hip: torch.Tensor, ref: torch.Tensor, fragile: torch.Tensor, bound: torch.Tensor = None,
+                         tol: float = None) -> dict:
     """The north star's bound, as the small-scene tests state it: <= 1e-4 relative (to max(|ref|, 1e-3)) on every pixel whose
     threshold decisions are not within the fp32 margin of their threshold (`fragile`, [H,W] bool from the oracle); the fragile
     pixels may flip one decision and are bounded absolutely.
     `bound` (same shape as ref; raster_ref.c `cond_bound`): what a couple of float ulps in the splats' stored screen-space
     centres do to the pixel, to first order.  A robust pixel beyond 1e-4 must be within 1e-4 + that bound
     (`conditioning_limited`: the rim of one or two faint splats, where any fp32 pipeline carries ~1e-4 per ulp of the centre);
-    what is beyond both is `unexplained`."""
+    what is beyond both is `unexplained`.  `tol`: IMAGE_TOL against the oracle in double; 2 x IMAGE_TOL against the oracle in
+    float, which is itself an fp32 evaluation within IMAGE_TOL of the exact value (triangle inequality)."""
+    tol = IMAGE_TOL if tol is None else tol
     a, b = hip.double(), ref.double()
     err = (a - b).abs()
     floor = b.abs().clamp_min(IMAGE_REL_FLOOR)
@@ -67,11 +70,11 @@ def image_figures_robust(hip: torch.Tensor, ref: torch.Tensor, fragile: torch.Te
            "fragile_max_abs": float(err[fr].max().item()) if fr.any() else 0.0,
            "median_rel": _pct(rel, 0.5)}
     if bound is not None:
-        beyond = above & (err > IMAGE_TOL * floor + bound.double())
+        beyond = above & (err > tol * floor + bound.double())
         out["conditioning_limited"] = out["robust_above_1e-4"] - int(beyond.sum().item())
         out["unexplained"] = int(beyond.sum().item())
         # how much of the allowance the worst such pixel uses (1.0 = at the bound)
-        out["max_err_over_allowance"] = float((err / (IMAGE_TOL * floor + bound.double()))[~fr].max().item()) if rob.numel() else 0.0
+        out["max_err_over_allowance"] = float((err / (tol * floor + bound.double()))[~fr].max().item()) if rob.numel() else 0.0
     else:
         out["unexplained"] = out["robust_above_1e-4"]
     return out
@@ -105,14 +108,17 @@ def radii_figures(hip_radii: torch.Tensor, ref_out: dict) -> dict:
     return res
 
 
-def compare_flagged(out: dict, grads: dict, ref_out: dict, ref_grads: dict) -> dict:
-    """compare() with the oracle's fragile mask, splat flags and conditioning bound (c_oracle.rasterize(..., fragile=True))."""
+def compare_flagged(out: dict, grads: dict, ref_out: dict, ref_grads: dict, oracle_precision: str = "fp64") -> dict:
+    """compare() with the oracle's fragile mask, splat flags and conditioning bound (c_oracle.rasterize(..., fragile=True)).
+    oracle_precision "fp32": the reference is itself an fp32 evaluation -- the image tolerance is two-sided (2 x IMAGE_TOL)."""
+    tol = IMAGE_TOL * (2.0 if oracle_precision == "fp32" else 1.0)
     fr, fl = ref_out["fragile"], ref_out["splat_flag"]
     cb = ref_out.get("cond_bound")
     bounds = {"color": None, "depth": None, "alpha": None} if cb is None else {"color": cb[0:3], "depth": cb[3:4], "alpha": cb[4:5]}
     rad = radii_figures(out["radii"], ref_out)
     res = {"radii_equal": rad["mismatches"] == 0, "radii": rad,
-           "images": {k: image_figures_robust(out[k], ref_out[k], fr, bounds[k]) for k in ("color", "depth", "alpha")},
+           "images": {k: image_figures_robust(out[k], ref_out[k], fr, bounds[k], tol) for k in ("color", "depth", "alpha")},
+           "image_tolerance": tol,
            "gradients": {k: grad_figures_flagged(grads[k], ref_grads[k], fl) for k in ref_grads if k in grads},
            "flagged_splat_share": float(fl.double().mean().item())}
     res["image_robust_max_rel"] = max(v["robust_max_rel"] for v in res["images"].values())

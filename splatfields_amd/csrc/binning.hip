@@ -289,13 +289,9 @@ __global__ void __launch_bounds__(kBlock) k_emit(const ViewK v, int N, const Geo
         // every 128-byte line of the segment would collect 8-byte pieces from all eight L2s and leave each of them as a
         // masked partial write (measured: 2.97x the algorithmic bytes).  Giving every XCD a contiguous band of chunks lets one
         // L2 assemble whole lines.
-#ifndef SR_EMIT_NO_XCD_BANDS
         const int per = (ch.chunks + 7) >> 3;
         const int chunk = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
         if ((int)(blockIdx.x >> 3) >= per || chunk >= ch.chunks) return;
-#else
-        const int chunk = (int)blockIdx.x;
-#endif
         slice = (uint32_t)(chunk % ch.slices); slices = (uint32_t)ch.slices;
         sb0 = (chunk / ch.slices) * ch.sub_per_chunk; sb1 = min(sb0 + ch.sub_per_chunk, ch.n_sub);
         const uint32_t* row = g.cnt + (size_t)chunk * ch.tiles_padded;

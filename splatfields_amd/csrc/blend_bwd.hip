@@ -58,9 +58,6 @@ static_assert(SR_BWD_CAP >= 256 && SR_BWD_CAP_DEPTH >= 256, "one quad's entries 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef SR_BWD_DIAG
-#define SR_BWD_DIAG 0   // timing experiments (wrong results): 1 no replay, 2 no scatter / gather, 4 no chunk gathers, 8 no slot stores
-#endif
 #ifdef SR_BWD_STATS
 // diagnostic build only (bench.py's pairs_evaluated / pairs_blended figures): [0] list entries tested, [1] (quad, entry)
 // pairs, [2] buckets, [3] (pixel, entry) pairs evaluated, [4] pairs blended (alpha >= 1/255 and not behind the pixel's
@@ -89,31 +86,6 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint
 // the total a bucket leaves in its last lane is already where the next bucket's first entry picks it up: no lane
 // broadcast, no rotate.
 constexpr int kShl1 = 0x101, kShl2 = 0x102, kShl4 = 0x104, kShl8 = 0x108;
-#ifdef SR_BWD_SCAN_SHFL
-// reference implementation of the row scans (ds_bpermute): debugging aid, selected at build time
-template <bool UP> __device__ __forceinline__ float row_scan_add(float x) {
-    const int n = threadIdx.x & 15;
-    for (int d = 1; d < 16; d <<= 1) {
-        const float y = UP ? __shfl_up(x, d, 16) : __shfl_down(x, d, 16);
-        if (UP ? n >= d : n + d < 16) x += y;
-    }
-    return x;
-}
-template <bool UP> __device__ __forceinline__ float row_scan_mul(float x) {
-    const int n = threadIdx.x & 15;
-    for (int d = 1; d < 16; d <<= 1) {
-        const float y = UP ? __shfl_up(x, d, 16) : __shfl_down(x, d, 16);
-        if (UP ? n >= d : n + d < 16) x *= y;
-    }
-    return x;
-}
-// UP: lane 0 keeps `carry` (its own lane's value), lane l >= 1 gets v of lane l - 1; DOWN: mirrored
-template <bool UP> __device__ __forceinline__ float shift_in_carry(float carry, float v) {
-    const int n = threadIdx.x & 15;
-    const float y = UP ? __shfl_up(v, 1, 16) : __shfl_down(v, 1, 16);
-    return (UP ? n == 0 : n == 15) ? carry : y;
-}
-#else
 // inclusive prefix over each row of 16 lanes (Kogge-Stone, 4 DPP steps)
 template <bool UP> __device__ __forceinline__ float row_scan_add(float x) {
     if (UP) { x += dpp_f<kShr1>(0.f, x); x += dpp_f<kShr2>(0.f, x); x += dpp_f<kShr4>(0.f, x); x += dpp_f<kShr8>(0.f, x); }
@@ -142,7 +114,6 @@ template <bool UP> __device__ __forceinline__ float row_scan_mul(float x) {
 template <bool UP> __device__ __forceinline__ float shift_in_carry(float carry, float v) {
     return UP ? dpp_f<kShr1>(carry, v) : dpp_f<kShl1>(carry, v);
 }
-#endif
 
 // x, y hold two different quantities per lane.  swap32: r[l] = x[l] + x[l + 32] for l < 32, y[l - 32] + y[l] above (one
 // v_permlane32_swap + one add: each half-wave now owns one quantity); swap16 the same one level down (rows 0, 2 own x, rows
@@ -320,14 +291,10 @@ struct QuadCtx {
     "v_mul_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t" \
     "v_mul_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
 template <bool UP> __device__ __forceinline__ void row_scan_mul4(float (&x)[4]) {
-#ifdef SR_BWD_SCAN_SHFL
-    for (int t = 0; t < 4; ++t) x[t] = row_scan_mul<UP>(x[t]);
-#else
     if (UP) asm("s_nop 1\n\t" SR_DPP_MUL4("row_shr:1") SR_DPP_MUL4("row_shr:2") SR_DPP_MUL4("row_shr:4") SR_DPP_MUL4("row_shr:8")
                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
     else asm("s_nop 1\n\t" SR_DPP_MUL4("row_shl:1") SR_DPP_MUL4("row_shl:2") SR_DPP_MUL4("row_shl:4") SR_DPP_MUL4("row_shl:8")
              : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-#endif
 }
 #define SR_DPP_ADD4(ctrl) \
     "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -337,14 +304,10 @@ template <bool UP> __device__ __forceinline__ void row_scan_mul4(float (&x)[4]) 
 // the sum scan the same way (left to the compiler, its scheduler puts the four columns' scans one after the other again to
 // save registers, with wait states between the levels)
 template <bool UP> __device__ __forceinline__ void row_scan_add4(float (&x)[4]) {
-#ifdef SR_BWD_SCAN_SHFL
-    for (int t = 0; t < 4; ++t) x[t] = row_scan_add<UP>(x[t]);
-#else
     if (UP) asm("s_nop 1\n\t" SR_DPP_ADD4("row_shr:1") SR_DPP_ADD4("row_shr:2") SR_DPP_ADD4("row_shr:4") SR_DPP_ADD4("row_shr:8")
                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
     else asm("s_nop 1\n\t" SR_DPP_ADD4("row_shl:1") SR_DPP_ADD4("row_shl:2") SR_DPP_ADD4("row_shl:4") SR_DPP_ADD4("row_shl:8")
              : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-#endif
 }
 
 template <bool UP, bool HAS_D>
@@ -356,10 +319,6 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
     pair_alpha_row(c.Y, e.E0, e.F0, e.ps, e.q, e.nlo, G0, K);
 #pragma unroll
     for (int t = 0; t < 4; ++t) oG[t] = pair_alpha_px(c.Xa[t], e.p, G0, K);
-#if SR_BWD_DIAG & 64
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { const float tt = fmaf(-e.p, c.Xa[t], G0); oG[t] = fmaf(tt, tt, K) * 0.001f; }   // timing experiment: no v_exp
-#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool hit = (oG[t] >= kAlphaMin) && (e.pos < c.last[t]);
@@ -371,11 +330,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
 #pragma unroll
     for (int t = 0; t < 4; ++t) alpha[t] = fminf(oGc[t], kAlphaMax);   // oGc >= 0
 #pragma unroll
-#if SR_BWD_DIAG & 64
-    for (int t = 0; t < 4; ++t) ginv[t] = 1.0f + alpha[t];   // timing experiment: no v_rcp
-#else
     for (int t = 0; t < 4; ++t) ginv[t] = __builtin_amdgcn_rcpf(1.0f - alpha[t]);
-#endif
     // (colour . upstream gradient) of every pixel: independent of the chain above, fills its gaps
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -387,9 +342,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
     // transmittance in front of entry n: T_n = (T behind the bucket) * prod_{j <= n} 1 / (1 - alpha_j)
 #pragma unroll
     for (int t = 0; t < 4; ++t) x[t] = shift_in_carry<UP>(ST[t], ginv[t]);
-#if !(SR_BWD_DIAG & 32)
     row_scan_mul4<UP>(x);
-#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) { T[t] = x[t] * ginv[t]; ST[t] = T[t]; }   // last lane of the scan: behind the next bucket
 #pragma unroll
@@ -397,9 +350,7 @@ __device__ __forceinline__ BucketSums replay_bucket(const QuadCtx& c, const Slot
     // (colour accumulated behind entry n, incl. background) . upstream gradient
 #pragma unroll
     for (int t = 0; t < 4; ++t) y[t] = shift_in_carry<UP>(SB[t], z[t]);
-#if !(SR_BWD_DIAG & 32)
     row_scan_add4<UP>(y);
-#endif
     // The ten sums over the quad's pixels.  Per lane (one pixel row, four columns): moments of g1 in X about the tile centre
     // and the colour / depth sums of the weights; the row's Y is a per-lane constant applied afterwards; then the four rows of
     // the wavefront are added with eight swap-adds (swap32_sum / swap16_sum).
@@ -487,17 +438,11 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
     if (bmax == 0) return;   // uniform: empty list, or no pixel of the tile blended anything
     int hi = bmax;   // list entries [0, hi) are still to be replayed (back to front)
     const uint32_t* qms = b.qmask + start;
-#ifndef SR_BWD_EARLY_PIX
-#define SR_BWD_EARLY_PIX 0   // 1: the per-pixel inputs are requested BETWEEN the splat-index load and the record gather that depends
-#endif                       //    on it (one memory round trip less in a tile's preamble on paper); 0: behind the gather.
-                             //    Measured in round 5 (same box, alternated): 0.1977 vs 0.1933 ms, SLOWER -- the record gather is
-                             //    what the first chunk waits for, and six more requests per lane in front of it delay it
-
+    // (the per-pixel inputs are requested BEHIND the record gather: in front of it -- one memory round trip less in a tile's
+    // preamble on paper -- they delay the gather the first chunk waits for: 0.1977 vs 0.1933 ms, round 5)
     const uint32_t id_first = ids[max(hi - 1 - tid, 0)];
     uint32_t id_next = ids[max(hi - kChunk - 1 - tid, 0)];   // its splat index: loaded another chunk earlier
-#if !SR_BWD_EARLY_PIX
     BwdEntry cur = load_entry(g, id_first, qms, hi - 1 - tid);
-#endif
 
     // ---- per-pixel inputs: thread i <-> pixel (i & 15, i >> 4) of the tile ----
     {
@@ -520,9 +465,6 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
         if (threadIdx.x < 2) s_ticket[threadIdx.x] = 0u;
         // no barrier here: the first readers of these tables (replay) sit behind the two barriers of the first chunk
     }
-#if SR_BWD_EARLY_PIX
-    BwdEntry cur = load_entry(g, id_first, qms, hi - 1 - tid);
-#endif
 
     const int k = lane >> 4, nl = lane & 15;
     const uint32_t lt_mask = (1u << (lane & 31)) - 1u;   // earlier entries of this thread's block
@@ -614,9 +556,6 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
         auto combine = [&](uint32_t pmask) {
             if (cur.pos >= 0) {
                 uint32_t m = qm & pmask;
-#if SR_BWD_DIAG & 2
-                m = 0u;   // timing experiment: no gather of the sums
-#endif
                 while (m) {
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
@@ -637,9 +576,6 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
             if (q_lo == 0) finish_entry(cur, (uint32_t)tx, (uint32_t)ty);   // first use of the gathered record
             {
                 uint32_t m = qm & pmask;
-#if SR_BWD_DIAG & 2
-                m = 0u;   // timing experiment: no record scatter
-#endif
                 while (m) {
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
@@ -667,9 +603,6 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
                 const int qy = q >> 2, qx = q & 3;
                 const int len = __builtin_amdgcn_readfirstlane((int)s_qlen[par][q]);
                 if (len == 0) continue;
-#if SR_BWD_DIAG & 1
-                continue;   // timing experiment: no replay
-#endif
                 const int base = __builtin_amdgcn_readfirstlane((int)s_qbase[par][q]);
                 const int prow = (4 * qy + k) * 16 + 4 * qx;   // tile-local index of pixel (t = 0, row k) of the quad
                 QuadCtx c;
@@ -748,11 +681,7 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
         const size_t inst = cur.inst;
         const bool has_entry = cur.pos >= 0;
         // shift the moments to the splat centre and store the instance's gradient slot
-#if SR_BWD_DIAG & 8
-        if (has_entry && s0.x == 12345.678f) {   // timing experiment: (practically) no slot stores
-#else
         if (has_entry) {
-#endif
             // moments about the tile centre (X, Y = pixel - centre) -> sums of g1 dx^a dy^b with dx = cx - pixel x = ox - X
             const float ox = centre.x - (tx0f + 7.5f), oy = centre.y - (ty0f + 7.5f);
             const float M0 = s0.x, MX = s0.y, MY = s0.z, MXX = s0.w, MXY = s1.x, MYY = s1.y;
@@ -765,14 +694,10 @@ k_render_backward_quads(const ViewK v, const Geom g, const Binning b, const Imag
             slot4[inst * kSlotF4 + 2] = make_float4(s2.x, s2.y, 0.f, 0.f);
             b.reached[inst] = 1;
         }
-#if SR_BWD_DIAG & 4
-        if (hi > 0) cur.pos = hi - 1 - tid;   // timing experiment: no gather for the following chunks
-#else
         if (hi > 0) {   // uniform condition
             cur = load_entry(g, id_next, qms, hi - 1 - tid);
             id_next = ids[max(hi - kChunk - 1 - tid, 0)];
         }
-#endif
         SR_PHASE(7);   // (E) combine
     }
 #ifdef SR_BWD_STATS

@@ -63,14 +63,8 @@ struct Geom {
     uint32_t* segbase;       // extent of rounds 2-4 for both tables (workspace sizes are part of the callers' contract); segbase is unused
 };
 
-#ifndef SR_MAX_CHUNKS
-#define SR_MAX_CHUNKS 1024
-#endif
-constexpr int kMaxChunks = SR_MAX_CHUNKS;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
-#ifndef SR_SEG_ROWS
-#define SR_SEG_ROWS 128
-#endif
-constexpr int kSegRows = SR_SEG_ROWS;   // chunks per column-scan segment
+constexpr int kMaxChunks = 1024;        // chunk = consecutive 256-splat sub-batches handled by one workgroup
+constexpr int kSegRows = 128;   // chunks per column-scan segment
 constexpr int kMaxMatrixTiles = 16384;  // LDS histogram of 64 KiB; larger images use the global-atomic fallback
 
 // A chunk = `sub_per_chunk` consecutive sub-batches, or -- when there are fewer than kMaxChunks / 2 sub-batches -- one of
@@ -85,9 +79,7 @@ inline Chunking make_chunking(int N, int tiles) {
     c.sub_per_chunk = (c.n_sub + b - 1) / b;
     c.chunks = (c.n_sub + c.sub_per_chunk - 1) / c.sub_per_chunk;
     c.slices = 1;
-#ifndef SR_NO_CHUNK_SLICES
     if (c.sub_per_chunk == 1) { c.slices = kMaxChunks / c.chunks; if (c.slices > 8) c.slices = 8; if (c.slices < 1) c.slices = 1; }
-#endif
     c.chunks *= c.slices;
     c.segments = (c.chunks + kSegRows - 1) / kSegRows;
     c.tiles_padded = (tiles + 63) / 64 * 64;
@@ -196,12 +188,9 @@ inline size_t carve_image(void* base, int H, int W, Image* im) {
 // backward blend and read by k_preprocess_backward; Binning::reached says which.
 // Slot stride = kSlotF4 quarters of 16 bytes.  Memory is written and fetched in 64-byte sectors, and a 48-byte stride puts half
 // of the slots across two of them (backward blend: WRITE_SIZE 168 MB for 82 MB of slots).  A 64-byte stride was measured
-// (round 4, SR_SLOT_F4=4): the backward blend does not care (0.2556 vs 0.2558 ms), and k_preprocess_backward gets SLOWER
+// (round 4): the backward blend does not care (0.2556 vs 0.2558 ms), and k_preprocess_backward gets SLOWER
 // (0.0978 vs 0.0945 ms) -- it reads a splat's consecutive instances, which the 48-byte stride packs into fewer sectors.
-#ifndef SR_SLOT_F4
-#define SR_SLOT_F4 3
-#endif
-constexpr int kSlotF4 = SR_SLOT_F4;
+constexpr int kSlotF4 = 3;
 constexpr int kSlotFloats = 4 * kSlotF4;
 
 
@@ -405,14 +394,8 @@ __device__ __forceinline__ bool subtile_overlap(const float4 r0, const float4 r1
 // is already the bounding box of the support), and the test -- plus 32 bytes of record per splat in the two passes that
 // apply it -- costs more than the few entries it removes (headline workload, test on every instance: +18 us for -15 us;
 // from 4 tiles on: step -0.5 %, dense scenes -3.5 %, their sort -27 %).
-#ifndef SR_CULL_MIN_TILES
-#define SR_CULL_MIN_TILES 4
-#endif
-constexpr uint32_t kCullMinTiles = SR_CULL_MIN_TILES;
-#ifndef SR_DIRECT_TILES
-#define SR_DIRECT_TILES 9
-#endif
-constexpr uint32_t kDirectTiles = SR_DIRECT_TILES;   // rectangles up to this many tiles are walked by their own thread in the two instance passes
+constexpr uint32_t kCullMinTiles = 4;
+constexpr uint32_t kDirectTiles = 9;   // rectangles up to this many tiles are walked by their own thread in the two instance passes
                                                     // (round 4, headline scan + emit: 4 -> +1.3 us, 6 -> -3.3, 9 -> -4.4, 16 -> -4.4; dense 100 k x 0.05: +1)
 // Rectangles of up to kMaskTiles tiles get the outcome of the test once, in k_preprocess: bit k of the mask = tile k of the
 // rectangle (row-major) can be reached (all ones below kCullMinTiles).  The two instance passes read the bit instead of the
@@ -420,15 +403,9 @@ constexpr uint32_t kDirectTiles = SR_DIRECT_TILES;   // rectangles up to this ma
 // scatter cannot disagree.  The 16 bits (bit 15 = mask present, bits 0..14 = mask) ride in the top nibbles of the four
 // 16-bit fields of Geom::rect (tile coordinates are < 4096: images up to 65520 pixels a side, checked by the C ABI).
 // (Packed into Geom::touched they cost k_preprocess_backward 2.4 us: its loads queued behind the decode of that word.)
-#ifndef SR_MASK_TILES
-#define SR_MASK_TILES 9
-#endif
-constexpr uint32_t kMaskTiles = SR_MASK_TILES;   // <= 15 (the mask has 15 bits).  Measured 9 vs 15: headline equal; 100 k x 0.05: k_preprocess +1.9 vs +4.5 us
+constexpr uint32_t kMaskTiles = 9;   // <= 15 (the mask has 15 bits).  Measured 9 vs 15: headline equal; 100 k x 0.05: k_preprocess +1.9 vs +4.5 us
                                                  // (a wavefront pays the longest mask loop of its 64 splats)
-#ifndef SR_MASK_MIN_TILES
-#define SR_MASK_MIN_TILES 1
-#endif
-constexpr uint32_t kMaskMinTiles = SR_MASK_MIN_TILES;   // masked rectangles of at least this many tiles are tested tile by tile: every one.
+constexpr uint32_t kMaskMinTiles = 1;   // masked rectangles of at least this many tiles are tested tile by tile: every one.
                                                        // (With the test paid once, the one- to three-tile rectangles are worth it too -- 4 / 2 / 1: k_preprocess
                                                        // +0 / +1.7 / +1.7 us, scatter + sort + blend pair -0 / -2.3 / -4.3 us at the headline.)
 constexpr uint32_t kRectMasked = 0x8000u;

@@ -137,16 +137,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     __shared__ ushort4 s_rect[COUNT_ATOMIC ? kBlock : 1];
     __shared__ float4 s_r0[COUNT_ATOMIC ? kBlock : 1], s_r1[COUNT_ATOMIC ? kBlock : 1];   // ellipses for the tile_reached test
     __shared__ uint32_t s_scan[8];
-#ifndef SR_PRE_REC_T
-#define SR_PRE_REC_T 1   // 1: the 64-byte records leave through LDS, quarter-major with a padded row: consecutive lanes store
-#endif                   //    consecutive 16-byte pieces of the workgroup's contiguous 16 KB (whole lines per wave-instruction);
-                         //    0: every thread stores its own four quarters (16-byte pieces at a 64-byte stride: the L2 has to
-                         //    assemble every line from four partial writes; rounds 1-4)
+    // The 64-byte records leave through LDS, quarter-major with a padded row: consecutive lanes store consecutive 16-byte pieces
+    // of the workgroup's contiguous 16 KB -- whole lines per wave-instruction.  (Rounds 1-4: every thread stored its own four
+    // quarters, 16-byte pieces at a 64-byte stride, and the L2 had to assemble every line from four partial writes.)
     // float4 per quarter row.  Lane l of the transposed read takes quarter l & 3 of record l >> 2: eight consecutive lanes -- one
     // 128-byte LDS pass -- hit the 16-byte bank groups (q R + r) mod 8, q = 0..3, r = 0..1, which are all different iff
     // R = 2 (mod 8).  (Round 5 padded by 1: lanes 1..3 of a record shared their groups with lanes 4..6 of the next one.)
     constexpr int kRecRow = kBlock + 2;
-    constexpr int kRecF4 = SR_PRE_REC_T ? 4 * kRecRow : 1;
+    constexpr int kRecF4 = 4 * kRecRow;
     __shared__ float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : kRecF4];   // SH staging first; the records' transpose afterwards
     static_assert(!STAGE_SH || kBlock * kShRowF4 >= kRecF4, "the record transpose reuses the SH staging area");
 
@@ -356,9 +354,13 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
     uint32_t total;
     const uint32_t excl = block_exclusive_scan(touched, s_scan, total);
     if (threadIdx.x == 0) g.block_sums[blockIdx.x] = total;
-#if SR_PRE_REC_T
     {
         // (block_exclusive_scan's barriers lie behind every thread's last read of the SH rows: the area is free)
+        // The record is always written whole (a line with a 16-byte hole leaves the L2 as a masked partial write, which costs
+        // more than the 16 bytes).  q3 = (tile rect origin, rect width, first instance of the splat RELATIVE to its 256-splat
+        // sub-batch, 0): the backward blend derives a (splat, tile) pair's instance index from it as block_offsets[splat >> 8] +
+        // q3.z + position of the tile in the rect -- a 16 KB table that lives in the caches instead of a 4-byte gather per list
+        // entry into the 4 MB `offsets` array (one line of HBM traffic each).
         float4* s_rec = s_sh;
         const float4 q3 = make_float4(__uint_as_float(rect_bits), __uint_as_float((uint32_t)(rect.z - rect.x)), __uint_as_float(excl), 0.f);
         // a splat without a record (culled, or no tile) stores the "never visible" defaults: nothing ever gathers its record
@@ -371,21 +373,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess(const ViewK v, const Spla
             const int G = j * kBlock + (int)threadIdx.x;       // float4 index inside the workgroup's block: record G / 4, quarter G % 4
             if (G < 4 * n_here) out[G] = s_rec[(G & 3) * kRecRow + (G >> 2)];
         }
-    }
-    if (false) {
-#else
-    if (write_rec) {
-#endif
-        // The 64-byte record, written whole (a line with a 16-byte hole leaves the L2 as a masked partial write, which costs
-        // more than the 16 bytes: 0.087 -> 0.078 ms for this kernel).  q3 = (tile rect origin, rect width, first instance of
-        // the splat RELATIVE to its 256-splat sub-batch, 0): the backward blend derives a (splat, tile) pair's instance index
-        // from it as block_offsets[splat >> 8] + q3.z + position of the tile in the rect -- a 16 KB table that lives in the
-        // caches instead of a 4-byte gather per list entry into the 4 MB `offsets` array (one line of HBM traffic each).
-        float4* rec = g.rec + 4 * (size_t)idx;
-        rec[0] = ell0;
-        rec[1] = ell1;
-        rec[2] = rec2;
-        rec[3] = make_float4(__uint_as_float(rect_bits), __uint_as_float((uint32_t)(rect.z - rect.x)), __uint_as_float(excl), 0.f);
     }
     if constexpr (COUNT_ATOMIC) {
         // fallback for very large images: per-tile counts with global atomics
@@ -465,17 +452,11 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                                                                 const int first_splat, const int end_splat) {
     // splats [first_splat, end_splat) of the cloud (first_splat a multiple of 256): the whole cloud in one launch, or one
     // slice of it per launch when the caller overlaps an exchange of the finished slices with the rest (sr_backward_splats)
-#ifndef SR_PREB_T3
-#define SR_PREB_T3 0   // 1: the three [N,3] gradient tensors (means3D, means2D, scales) leave through LDS as whole 16-byte pieces of
-#endif                 //    the workgroup's contiguous 3 KB blocks (needs 16-byte aligned tensors); 0: three 4-byte stores at a
-                       //    12-byte stride per tensor and thread (every line assembled by the L2 from three partial writes).
-                       //    Measured in round 5 (same box, alternated three times): 0.1038 vs 0.0955 ms, SLOWER (precomputed
-                       //    colours 0.0513 vs 0.0491): the transpose has to wait for the SH gradient to leave the staging area
-                       //    (two more barriers), so the small stores move from the middle of the workgroup's life -- where they
-                       //    overlapped the 48 KB stage-out -- to its very end.  The same idea in k_preprocess (SR_PRE_REC_T,
-                       //    64-byte records at a 64-byte stride -> whole lines) sits at the end of the kernel anyway and gains 3 us
-    constexpr int kT3Floats = SR_PREB_T3 ? 3 * 3 * kBlock : 4;
-    __shared__ __attribute__((aligned(16))) float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : (kT3Floats + 3) / 4];
+    // (The three [N,3] gradient tensors leave as three 4-byte stores at a 12-byte stride per tensor and thread.  Sending them
+    // through LDS as whole 16-byte pieces -- the transpose that gives k_preprocess 3 us -- was measured in round 5: SLOWER, 0.1038 vs
+    // 0.0955 ms: it has to wait for the SH gradient to leave the staging area, which moves the small stores from the middle of
+    // the workgroup's life to its very end.)
+    __shared__ __attribute__((aligned(16))) float4 s_sh[STAGE_SH ? kBlock * kShRowF4 : 1];
     const int idx = first_splat + blockIdx.x * kBlock + threadIdx.x;
     const bool valid = idx < end_splat;
     int radius_in = 0;
@@ -509,22 +490,14 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     // Which of the splat's instances hold a gradient slot: the backward blend wrote one (and set the instance's `reached` byte)
     // for every list entry in front of the stop of its tile's last pixel; the others are neither written nor read.  The bytes
     // of the first 4 instances are requested now, together with the splat's own loads (most splats have <= 4 instances).
-#ifndef SR_PREB_DIAG
-#define SR_PREB_DIAG 0   // timing experiments (wrong results): 1 no `reached` / slot reads, 2 no SH-gradient stage-out, 4 no small stores
-#endif
-    const bool vis_in = valid && radius_in > 0 && !(SR_PREB_DIAG & 1);
-#ifndef SR_PREB_SPEC
-#define SR_PREB_SPEC 1   // 1: the gradient slots of a splat's first four instances are requested TOGETHER with their `reached` bytes,
-#endif                   //    before anything looks at the bytes (one memory round trip instead of two: offsets -> {reached, slots}
-                         //    instead of offsets -> reached -> slots); a slot the backward blend did not write holds stale bytes and
-                         //    is dropped by its byte.  0: slots requested once their byte is known (rounds 3-4).
-                         //    Round 5, same box, alternated: 0.0941 -> 0.0857 ms.  (A first version issued the slot requests BEHIND
-                         //    the or-ing of the bytes, i.e. behind the wait for them, and measured nothing: the kernel is a chain of
-                         //    dependent memory round trips per workgroup -- timing builds without the slot reads, without the SH
-                         //    stage-out and without the small stores take 0.067 / 0.068 / 0.088 ms: the parts ADD, three workgroups
-                         //    per CU do not overlap them -- and every round trip taken out of the chain is time.)
+    const bool vis_in = valid && radius_in > 0;
+    // The gradient slots of a splat's first four instances are requested TOGETHER with their `reached` bytes, before anything looks
+    // at the bytes (one memory round trip instead of two: offsets -> {reached, slots} instead of offsets -> reached -> slots); a
+    // slot the backward blend did not write holds stale bytes and is dropped by its byte.  Round 5, same box, alternated: 0.0941 ->
+    // 0.0857 ms -- the kernel is a chain of dependent memory round trips per workgroup (timing builds without the slot reads,
+    // without the SH stage-out and without the small stores: 0.067 / 0.068 / 0.088 ms; the parts ADD), and every round trip taken
+    // out of the chain is time.
     uint32_t reached4 = 0u;
-#if SR_PREB_SPEC
     // Only for small footprints -- a template parameter, chosen by the host with the rule that picks the backward blend kernel (at
     // most SR_BWD_WAVE_KERNEL_ABOVE instances per splat on average): with 15 instances per splat (300 k x 0.02) the speculative
     // form is SLOWER, 0.0787 vs 0.0680 ms (most of a splat's slots are then fetched by the loop below anyway), and a run-time
@@ -552,13 +525,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
             for (uint32_t i = 0; i < 4; ++i) if (i <= lasti) reached4 |= rb[i] << (8 * i);
         }
     }
-#else
-    if (vis_in) {
-#pragma unroll
-        for (uint32_t i = 0; i < 4; ++i)
-            if (i < cnt_in) reached4 |= (uint32_t)reached[first_in + i] << (8 * i);
-    }
-#endif
     // ---- segmented reduction of every splat's instance slots (fixed order -> deterministic) ----
     // Splats with many instances (large footprints; dense real scenes) are reduced by the whole wavefront, 64
     // instances per step + one DPP reduction, instead of serialising hundreds of iterations in one lane.
@@ -593,7 +559,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         }
         if (vis_in && !big) {
             const float4* sl = sl_all + (size_t)first_in * kSlotF4;
-#if SR_PREB_SPEC
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i) {   // same order of additions as the loop below: bit-identical sums
                 if (use_spec && i < cnt_in && ((reached4 >> (8 * i)) & 0xffu) != 0u) {
@@ -604,9 +569,6 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
                 }
             }
             for (uint32_t i = use_spec ? 4u : 0u; i < cnt_in; ++i) {
-#else
-            for (uint32_t i = 0; i < cnt_in; ++i) {
-#endif
                 const bool hit = i < 4u ? ((reached4 >> (8 * i)) & 0xffu) != 0u : reached[first_in + i] != 0;
                 if (!hit) continue;
                 const float4 a = sl[kSlotF4 * i], b4 = sl[kSlotF4 * i + 1], c4 = sl[kSlotF4 * i + 2];
@@ -692,26 +654,13 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     auto stage_out_part = [&]() {
         __syncthreads();
         const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
-#if SR_PREB_DIAG & 2
-        if (s_sh[threadIdx.x].x == 12345.678f)
-#endif
         {
         if (gr.shs_rest) stage_sh_out_split(s_sh, gr.shs, gr.shs_rest, first, min(kBlock, end_splat - (int)first));
         else stage_sh_out(s_sh, gr.shs, first, min(kBlock, end_splat - (int)first));
         }
     };
-#ifndef SR_PREB_COLFIRST
-#define SR_PREB_COLFIRST 0   // 1: the SH gradient -- 192 of the 248 bytes a splat writes; it needs only the colour sums and the view
-#endif                       //    direction -- is computed, staged and STORED first, and the covariance chain rule runs while those
-                             //    stores drain (stores are fire-and-forget); 0: everything computed, then the store burst at the
-                             //    very end of the workgroup's life.  Measured in round 5 (alternated three times): 0.0837 vs 0.0825
-                             //    ms -- nothing: a wavefront does not wait for its stores anyway, and the CU's other workgroups were
-                             //    already computing beside the burst.  Off
-    constexpr bool kColourFirst = STAGE_SH && !SH_TO_COLORS && SR_PREB_COLFIRST;
-    if constexpr (kColourFirst) {
-        if (valid) colour_part();
-        stage_out_part();
-    }
+    // (Computing, staging and storing the SH gradient FIRST, with the covariance chain rule running while those stores drain, was
+    // measured in round 5: 0.0837 vs 0.0825 ms, nothing -- a wavefront does not wait for its stores anyway.)
     if (valid) {
     const float* vm = v.viewmatrix;
     const float* pm = v.projmatrix;
@@ -832,7 +781,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
         }
     }
 
-    if constexpr (!kColourFirst) colour_part();
+    colour_part();
     d_mean.x += dm_dir.x; d_mean.y += dm_dir.y; d_mean.z += dm_dir.z;
     if (s.raw) {  // derivatives of the activations: gradients w.r.t. the raw parameters
         if (s.raw & SR_RAW_SCALES) { d_scale.x *= sc_in.x; d_scale.y *= sc_in.y; d_scale.z *= sc_in.z; }   // d exp = exp
@@ -846,47 +795,16 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     }
     if (gr.colors) { gr.colors[3 * idx] = d_rgb.x; gr.colors[3 * idx + 1] = d_rgb.y; gr.colors[3 * idx + 2] = d_rgb.z; }
 
-#if SR_PREB_DIAG & 4
-    if (d_mean.x == 12345.678f)
-#endif
     {
-#if !SR_PREB_T3
     gr.means3D[3 * idx] = d_mean.x; gr.means3D[3 * idx + 1] = d_mean.y; gr.means3D[3 * idx + 2] = d_mean.z;
     gr.means2D[3 * idx] = d_m2d.x; gr.means2D[3 * idx + 1] = d_m2d.y; gr.means2D[3 * idx + 2] = 0.f;
     if (gr.scales) { gr.scales[3 * idx] = d_scale.x; gr.scales[3 * idx + 1] = d_scale.y; gr.scales[3 * idx + 2] = d_scale.z; }
-#endif
     gr.opacity[idx] = d_opac;
     if (gr.rotations) reinterpret_cast<float4*>(gr.rotations)[idx] = d_rot;
     if (gr.cov3D) { for (int k = 0; k < 6; ++k) gr.cov3D[6 * (size_t)idx + k] = d_cov[k]; }
     }
     }  // valid
-    if constexpr (STAGE_SH && !SH_TO_COLORS && !kColourFirst) stage_out_part();
-#if SR_PREB_T3
-    {
-        // [N,3] tensors: thread t's three floats at floats 3t .. 3t + 2 of the workgroup's block (a 12-byte stride: conflict-free
-        // in LDS), read back as float4 by consecutive lanes.  The staging area doubles as the transpose buffer once the SH
-        // gradient has left it.
-        if constexpr (STAGE_SH && !SH_TO_COLORS) __syncthreads();
-        float* s_t = reinterpret_cast<float*>(s_sh);
-        const int t = (int)threadIdx.x;
-        s_t[3 * t] = d_mean.x; s_t[3 * t + 1] = d_mean.y; s_t[3 * t + 2] = d_mean.z;
-        s_t[3 * kBlock + 3 * t] = d_m2d.x; s_t[3 * kBlock + 3 * t + 1] = d_m2d.y; s_t[3 * kBlock + 3 * t + 2] = 0.f;
-        s_t[6 * kBlock + 3 * t] = d_scale.x; s_t[6 * kBlock + 3 * t + 1] = d_scale.y; s_t[6 * kBlock + 3 * t + 2] = d_scale.z;
-        __syncthreads();
-        const size_t first = (size_t)first_splat + (size_t)blockIdx.x * kBlock;
-        const int total_f = 3 * min(kBlock, end_splat - (int)first);   // floats of this workgroup's block in every [N,3] tensor
-        float* dst3[3] = {gr.means3D + 3 * first, gr.means2D + 3 * first, gr.scales ? gr.scales + 3 * first : nullptr};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (!dst3[a]) continue;
-            const int f0 = 4 * t;
-            if (f0 >= total_f) continue;
-            const float4 x = *reinterpret_cast<const float4*>(s_t + a * 3 * kBlock + f0);
-            if (f0 + 3 < total_f) *reinterpret_cast<float4*>(dst3[a] + f0) = x;
-            else { dst3[a][f0] = x.x; if (f0 + 1 < total_f) dst3[a][f0 + 1] = x.y; if (f0 + 2 < total_f) dst3[a][f0 + 2] = x.z; }
-        }
-    }
-#endif
+    if constexpr (STAGE_SH && !SH_TO_COLORS) stage_out_part();
 }
 
 void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g, const int* radii,
@@ -897,7 +815,7 @@ void launch_preprocess_backward(const ViewK& v, const SplatsK& s, const Geom& g,
     if (nb <= 0) return;
     const bool to_colors = s.shs && !gr.shs && gr.colors;
     const bool stage = s.shs && v.sh_coeffs == 16 && gr.shs;  // LDS rows only carry the SH gradient out (coalesced 16-byte stores)
-    const bool spec = small_footprint && SR_PREB_SPEC;
+    const bool spec = small_footprint && 1;
 #define SR_LAUNCH_PB(A, B, C) hipLaunchKernelGGL((k_preprocess_backward<A, B, C>), dim3(nb), dim3(kBlock), 0, st, v, s, g, radii, slots, reached, gr, first, end)
     if (to_colors && stage) { if (spec) SR_LAUNCH_PB(true, true, true); else SR_LAUNCH_PB(true, true, false); }
     else if (to_colors) { if (spec) SR_LAUNCH_PB(false, true, true); else SR_LAUNCH_PB(false, true, false); }

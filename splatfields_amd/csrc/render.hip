@@ -78,38 +78,24 @@ __device__ __forceinline__ void publish_tile_reach(const Geom& g, int tile, uint
 __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const Geom g, const Binning b, const Image im,
                                                            float* __restrict__ out_color, float* __restrict__ out_depth,
                                                            float* __restrict__ out_alpha) {
-#ifndef SR_FWD_BUFS
-#define SR_FWD_BUFS 1
-#endif
-#ifndef SR_FWD_QUADS
-#define SR_FWD_QUADS 1   // 1: every row of 16 lanes walks the entries of ITS 4x4 quad (round 4: 0.112 -> 0.091 ms); 0: all 64 lanes
-#endif                   //    walk the entries of the 8x8 sub-tile (rounds 1-3)
-#ifndef SR_FWD_BATCH
-#define SR_FWD_BATCH 256
-#endif
     // Staging area of one batch of the tile's list: the three hot quarters of every entry's record and its quad-reach mask.
-    // SR_FWD_BUFS copies of SR_FWD_BATCH entries.  Measured on MI355X (headline workload): 1 x 256 (12.5 KB of LDS, eight
-    // workgroups per CU) 0.115 ms; 2 x 256 with the next batch in flight during the blending (25 KB, six per CU) 0.134 ms
-    // -- the blend loop is issue-bound and lives on its occupancy, the other workgroups of the CU already cover a batch's
-    // gather; the first version (registers -> LDS, per-wave box tests, 12 KB) 0.120 ms.
-    constexpr int kB = SR_FWD_BATCH;
+    // ONE copy of 256 entries (12.5 KB of LDS, eight workgroups per CU).  (Two copies with the next batch in flight during the
+    // blending -- 25 KB, six per CU -- and the next batch travelling through registers were both measured and are slower or equal:
+    // the blend loop is issue-bound and lives on its occupancy, the CU's other workgroups already cover a batch's gather;
+    // NOTEBOOK.md, rejected tables of rounds 3 and 5.)
+    constexpr int kB = 256;
     static_assert(kB == 256 || kB == 128, "a batch is staged by four or by two wavefronts");
     constexpr int kStagers = kB / kWave;       // wavefronts that stage one batch
     constexpr uint32_t kStep = 4 / kStagers;   // a wavefront stages every kStep-th batch
-    __shared__ float4 s_r0[SR_FWD_BUFS][kB];
-    __shared__ float4 s_r1[SR_FWD_BUFS][kB];
-    __shared__ float4 s_r2[SR_FWD_BUFS][kB];
-    __shared__ uint16_t s_qm[SR_FWD_BUFS][kB];   // quad-reach mask of every staged entry (quadmask.h)
+    __shared__ float4 s_r0[1][kB];
+    __shared__ float4 s_r1[1][kB];
+    __shared__ float4 s_r2[1][kB];
+    __shared__ uint16_t s_qm[1][kB];   // quad-reach mask of every staged entry (quadmask.h)
     __shared__ uint32_t s_live[2][4];            // per batch parity and wavefront: does it still have accumulating pixels?
-#if SR_FWD_QUADS
     __shared__ uint8_t s_idx[4][4][kB + 4];      // per wavefront and quad of its sub-tile: the batch entries that reach the quad
                                                  // (+ 4: the pipelined walk reads its index two trips ahead)
-#endif
-#ifndef SR_FWD_PIPE
-#define SR_FWD_PIPE 1   // 1: the trip loop reads the index two trips and the record one trip ahead (software pipeline, two copies of
-#endif                  //    the body so that no register is copied); 0: index -> record -> arithmetic serially in every trip (round 4)
     // the pipelined walk fetches a record by an index byte it has not masked yet (a stale byte of s_idx): any byte must be a slot
-    static_assert(!SR_FWD_PIPE || !SR_FWD_QUADS || kB == 256, "the pipelined walk indexes the staging area with unmasked bytes: 256 slots");
+    static_assert(kB == 256, "the pipelined walk indexes the staging area with unmasked bytes: 256 slots");
 
     // (the three scalar loads are requested together and tested with one wait: written as `a > x || b > y` ahead of the tile
     // lookup they were three dependent memory round trips at the head of every workgroup)
@@ -136,13 +122,9 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     const int tx = tile % v.gx, ty = tile / v.gx;
     const int wave = __builtin_amdgcn_readfirstlane(wave_id()), lane = lane_id();
     const int sx = tx * kTile + (wave & 1) * kSub, sy = ty * kTile + (wave >> 1) * kSub;
-#if SR_FWD_QUADS
     // row j of 16 lanes = quad j of the sub-tile (4x4 pixels): every row walks ITS quad's entries
     const int qrow = lane >> 4;
     const int px = sx + 4 * (qrow & 1) + (lane & 3), py = sy + 4 * (qrow >> 1) + ((lane >> 2) & 3);
-#else
-    const int px = sx + (lane & 7), py = sy + (lane >> 3);
-#endif
     const bool inside = px < v.W && py < v.H;
     const float tx0f = (float)(tx * kTile), ty0f = (float)(ty * kTile);
     const float Xf = (float)(px - tx * kTile), Yf = (float)(py - ty * kTile);   // this lane's pixel relative to the tile
@@ -181,7 +163,6 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     // against the sixteen 4x4 quads, quadmask.h): LDS for this kernel's sub-tile culling, memory for the backward's bucketing
     auto publish_mask = [&](int buf, uint32_t i) {
         uint32_t qm = 0u;
-#ifndef SR_FWD_NO_QMASK
         if (i < end) {
             const float4 r0 = s_r0[buf][slot], r1 = s_r1[buf][slot];
             qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
@@ -193,30 +174,6 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
             *reinterpret_cast<float2*>(&s_r0[buf][slot]) = make_float2(E0, F0);
             s_r1[buf][slot].y = ps;
         }
-#endif
-        s_qm[buf][slot] = (uint16_t)qm;
-    };
-#ifndef SR_FWD_REGSTAGE
-#define SR_FWD_REGSTAGE 0   // 1: the NEXT batch's records travel into registers while the current batch is blended and are written
-#endif                      //    to the (single) staging area behind the batch's barrier: no memory round trip between two batches.
-                            //    0: LDS-direct copies requested behind the barrier (the gather's latency is exposed once per
-                            //    batch and covered by the CU's other workgroups).  Measured in round 5, same box, alternated
-                            //    three times: 0.0882 vs 0.0878 ms at the headline, 0.0638 vs 0.0631 / 0.0758 vs 0.0751 in the
-                            //    dense regimes -- the other workgroups DO cover it; the register form (64 registers, still eight
-                            //    wavefronts per SIMD) buys nothing and stays switched off
-    // the same from registers: the staged form of an entry -- (E0, F0, tau, depth) (p, p s, q, -log2 o) (r, g, b, depth) and its
-    // quad-reach mask -- written once
-    auto publish_regs = [&](int buf, uint32_t i, const float4 r0, const float4 r1, const float4 r2) {
-        uint32_t qm = 0u;
-        float4 s0 = r0, s1 = r1;
-        if (i < end) {
-            qm = sr_quad_mask(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, tx0f, ty0f);
-            b.qmask[i] = qm;
-            float E0, F0, ps;
-            exponent_terms(r0.x, r0.y, r1, tx0f, ty0f, E0, F0, ps);
-            s0.x = E0; s0.y = F0; s1.y = ps;
-        }
-        s_r0[buf][slot] = s0; s_r1[buf][slot] = s1; s_r2[buf][slot] = r2;
         s_qm[buf][slot] = (uint16_t)qm;
     };
     const uint32_t lastpos = end - 1u;
@@ -239,26 +196,11 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
     uint32_t k = 0;
     for (uint32_t base = start; base < end; base += kB, ++k) {
         const bool more = base + kB < end;   // uniform
-        const int buf = SR_FWD_BUFS == 2 ? (int)(k & 1u) : 0;
-        const int nbuf = SR_FWD_BUFS == 2 ? buf ^ 1 : 0;
+        constexpr int buf = 0, nbuf = 0;   // one staging copy
         // (The empty statement makes the compiler wait for the index load on EVERY path into the blend loop: it must not
         // believe a load is still pending there, or it protects the reuse of that register with a wait inside the loop.)
         asm volatile("" :: "v"(id_nxt));
-#if SR_FWD_BUFS == 2
-        // the other copy is free (every wavefront has passed the barrier behind its batch): start filling it
-        if (more && stages(k + 1u)) request(nbuf, id_nxt);
-#endif
-#if SR_FWD_REGSTAGE && SR_FWD_BUFS == 1
-        // the next batch's records: requested now, used behind this batch's barrier (twelve registers; ordinary loads, so the
-        // compiler's own wait in front of their first use is exact)
-        float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
-        if (more && stages(k + 1u)) {
-            const float4* rec = g.rec + 4 * (size_t)id_nxt;
-            nx0 = rec[0]; nx1 = rec[1]; nx2 = rec[2];
-        }
-#endif
         const int cnt = (int)min((uint32_t)kB, end - base);
-#if SR_FWD_QUADS
         if (livem != 0ull) {
             // Quad-granular walk: a splat's support is ~7 pixels wide, so of the entries that reach an 8x8 sub-tile most reach
             // one or two of its four quads -- walked by all 64 lanes, three quarters of them evaluate pixels the splat cannot
@@ -280,15 +222,11 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     qlen[j] += (uint32_t)__popcll(m);
                 }
             }
-#if defined(SR_FWD_DIAG) && (SR_FWD_DIAG & 1)
-            qlen[0] = qlen[1] = qlen[2] = qlen[3] = 0u;   // timing experiment: staging, masks and barriers only
-#endif
             wave_lds_fence();
             const uint32_t my_len = qrow == 0 ? qlen[0] : qrow == 1 ? qlen[1] : qrow == 2 ? qlen[2] : qlen[3];
             const uint32_t n_trip = (uint32_t)__builtin_amdgcn_readfirstlane((int)max(max(qlen[0], qlen[1]), max(qlen[2], qlen[3])));
             const uint8_t* my_idx = &s_idx[wave][qrow][0];
             const uint32_t posb = base - start;
-#if SR_FWD_PIPE
             // One trip = four entries (one per row of 16 lanes): index (1 byte) -> record (40 bytes) -> ~20 dependent VALU
             // instructions.  Read serially that is two LDS round trips in front of every trip's arithmetic; here the index of
             // trip i + 2 and the record of trip i + 1 are requested before trip i's arithmetic starts (LDS returns in order, so
@@ -331,95 +269,18 @@ __global__ void __launch_bounds__(kBlock) k_render_forward(const ViewK v, const 
                     ea = ea_n; eb = eb_n;
                 }
             }
-#else
-            for (uint32_t i = 0; i < n_trip; ++i) {
-                const uint32_t e = my_idx[i];                      // rows past their list read a stale index: masked below
-                const float2 ef = *reinterpret_cast<const float2*>(&s_r0[buf][e]);   // (E0, F0)
-                const float4 r1 = s_r1[buf][e], r2 = s_r2[buf][e];                     // (p, p s, q, -log2 o), (r, g, b, depth)
-                float G0, K;
-                pair_alpha_row(Yf, ef.x, ef.y, r1.y, r1.z, r1.w, G0, K);
-                const float alpha = fminf(kAlphaMax, pair_alpha_px(Xf, r1.x, G0, K));
-                const float test_T = T * (1.0f - alpha);
-                const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & __builtin_amdgcn_ballot_w64(i < my_len) & livem;
-                const uint64_t stopm = __builtin_amdgcn_ballot_w64(test_T < kTStop) & hitm;
-                const uint64_t blendm = hitm ^ stopm;  // stop implies hit
-                livem &= ~stopm;
-                const float w = mask_select(blendm, alpha * T, 0.0f);
-                Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r2.w, w, D);
-                T = mask_select(blendm, test_T, T);
-                if (stopm != 0ull) {   // rare: once per pixel at most
-                    last = mask_select(stopm, posb + e, last);
-                    if (livem == 0ull) break;
-                }
-            }
-#endif
         }
-#else
-        if (livem != 0ull) {
-            // 64 staged entries at a time: one lane looks at one entry's quad mask, the ballot is a scalar bit mask, and the
-            // wavefront walks its set bits -- uniform control flow, the LDS address of the next record is known without a
-            // dependent index load, the body is branch-free.
-            // (The loop is co-limited by the scalar unit: ~4.3 cycles per SALU instruction per SIMD on MI355X.)
-            for (int c = 0; c < cnt; c += kWave) {
-                const int el = c + lane;
-                const bool ok = el < cnt && ((uint32_t)s_qm[buf][el < cnt ? el : 0] & my_quads) != 0u;
-                uint64_t m = __builtin_amdgcn_ballot_w64(ok);
-#if defined(SR_FWD_DIAG) && (SR_FWD_DIAG & 1)
-                m = 0ull;   // timing experiment: staging, masks and barriers only
-#endif
-                const uint32_t pos0 = (base - start) + (uint32_t)c;
-                // (Two list entries per trip -- their six LDS reads issued together, the two exponent chains independent, the odd
-                // entry masked on the scalar unit -- was built in round 4: 0.1206 vs 0.1120 ms, SLOWER: the pairing costs more
-                // scalar instructions (two s_ff1, selects, a branch for the odd entry) than the shared latency gives back; with
-                // eight wavefronts per SIMD the other wavefronts already cover one entry's LDS round trip.)
-                while (m) {
-                    const int bit = (int)__builtin_ctzll(m);
-                    m &= ~(1ull << bit);
-                    const int e = c + bit;
-                    const float2 ef = *reinterpret_cast<const float2*>(&s_r0[buf][e]);   // (E0, F0)
-                    const float4 r1 = s_r1[buf][e], r2 = s_r2[buf][e];                     // (p, p s, q, -log2 o), (r, g, b, depth)
-                    float G0, K;
-                    pair_alpha_row(Yf, ef.x, ef.y, r1.y, r1.z, r1.w, G0, K);
-                    const float alpha = fminf(kAlphaMax, pair_alpha_px(Xf, r1.x, G0, K));
-                    const float test_T = T * (1.0f - alpha);
-                    const uint64_t hitm = __builtin_amdgcn_ballot_w64(alpha >= kAlphaMin) & livem;
-                    const uint64_t stopm = __builtin_amdgcn_ballot_w64(test_T < kTStop) & hitm;
-                    const uint64_t blendm = hitm ^ stopm;  // stop implies hit
-                    livem &= ~stopm;
-                    const float w = mask_select(blendm, alpha * T, 0.0f);
-                    Cr = fmaf(r2.x, w, Cr); Cg = fmaf(r2.y, w, Cg); Cb = fmaf(r2.z, w, Cb); D = fmaf(r2.w, w, D);
-                    T = mask_select(blendm, test_T, T);
-                    if (stopm != 0ull) last = mask_select(stopm, pos0 + (uint32_t)bit, last);  // rare: once per pixel at most
-                }
-                if (livem == 0ull) break;
-            }
-        }
-#endif
         if (!more) break;
         if (lane == 0) s_live[k & 1u][wave] = livem != 0ull ? 1u : 0u;
-#if SR_FWD_BUFS == 1
         lds_barrier();   // everybody is done with the batch: the one copy may be overwritten
         if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped
-#if !SR_FWD_REGSTAGE
         if (stages(k + 1u)) request(0, id_nxt);
-#endif
-#endif
-#if SR_FWD_REGSTAGE && SR_FWD_BUFS == 1
-        if (stages(k + 1u)) {
-            id_nxt = b.sorted_id[min(base + (1u + kStep) * kB + (uint32_t)slot, lastpos)];
-            publish_regs(0, base + kB + (uint32_t)slot, nx0, nx1, nx2);
-        }
-#else
         if (stages(k + 1u)) {
             lds_copy_wait();
             id_nxt = b.sorted_id[min(base + (1u + kStep) * kB + (uint32_t)slot, lastpos)];
             publish_mask(nbuf, base + kB + (uint32_t)slot);
         }
-#endif
         lds_barrier();
-#if SR_FWD_BUFS == 2
-        if ((s_live[k & 1u][0] | s_live[k & 1u][1] | s_live[k & 1u][2] | s_live[k & 1u][3]) == 0u) break;   // every pixel has stopped
-#endif
     }
     }
 done:
@@ -433,13 +294,8 @@ done:
         im.final_T[pix] = T;
         im.n_contrib[pix] = last;
     }
-#if SR_FWD_QUADS
     publish_tile_reach(g, tile, last, /*quad of this lane: */ 2 * (wave & 1) + (qrow & 1), 2 * (wave >> 1) + (qrow >> 1),
                        /*lane bits spanning a quad: */ 1, 2, 4, 8, (lane & 15) == 0);
-#else
-    publish_tile_reach(g, tile, last, /*quad of this lane: */ 2 * (wave & 1) + ((lane >> 2) & 1), 2 * (wave >> 1) + ((lane >> 5) & 1),
-                       /*lane bits spanning a quad: */ 1, 2, 8, 16, (lane & 0x1b) == 0);
-#endif
 }
 
 void launch_render_forward(const ViewK& v, const Geom& g, const Binning& b, const Image& im,

@@ -115,9 +115,12 @@ def record_observed(tag: str, figures: dict) -> None:
         pass
 
 
-XY_ULPS = 4.0   # float ulps of rounding assumed in a splat's stored screen-space centre (oracle/raster_ref.c `cond_bound`): HIP's
-                # ((x_ndc + 1) W - 1) / 2 in fp32 is within ~2.3 ulp of the exact value (tools/parity_fullsize.py, 32 comparisons),
-                # the fp32 oracle's own evaluation within 2
+# Float ulps of rounding assumed in a splat's stored screen-space centre (oracle/raster_ref.c `cond_bound`).  Against the oracle
+# in double only the HIP side rounds: its ((x_ndc + 1) W - 1) / 2 in fp32 sits within ~2.3 ulp of the exact value, and the worst
+# pixel of 32 full-size comparisons uses 0.92 of the allowance at 4 ulps (tools/parity_fullsize.py).  Against the oracle in float
+# BOTH sides are fp32 evaluations, each within 1e-4 (+ its own centre rounding) of the exact value: two-sided tolerance 2e-4 (oracle/
+# parity.py: compare_flagged(oracle_precision="fp32")) and 6 ulps.
+XY_ULPS = {"fp64": 4.0, "fp32": 6.0}
 
 
 def assert_parity_explained(out: dict, g: dict, sp: dict, st, grads, *, use_sh: bool, tag: str, precisions=("fp64", "fp32"),
@@ -125,7 +128,7 @@ def assert_parity_explained(out: dict, g: dict, sp: dict, st, grads, *, use_sh: 
     """The large-scene parity statement: against the C oracle in double AND in float, with the
     oracle's own account of what may legitimately differ between two fp32 evaluations,
       (a) every pixel whose threshold decisions are clear of their thresholds (not `fragile`) is within 1e-4 relative
-          (to max(|ref|, 1e-3): the north star's bound) plus the oracle's first-order bound for XY_ULPS ulps of rounding in the
+          (to max(|ref|, 1e-3): the north star's bound; against the oracle in float, itself an fp32 evaluation, 2e-4) plus the oracle's first-order bound for XY_ULPS float ulps of rounding in the
           splats' float screen-space centres -- a term that matters only where the rim of one or two faint splats is all a pixel
           shows -- and a fragile pixel is within one blended pair (2e-2 absolute);
       (b) every gradient element beyond 1e-3 of its tensor's maximum belongs to a splat that is blended into a fragile pixel
@@ -138,8 +141,8 @@ def assert_parity_explained(out: dict, g: dict, sp: dict, st, grads, *, use_sh: 
     figs = {}
     for prec in precisions:
         ref, rg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=threads,
-                                        precision=prec, fragile=True, xy_ulps=XY_ULPS)
-        fig = P.compare_flagged(out, g, ref, rg)
+                                        precision=prec, fragile=True, xy_ulps=XY_ULPS[prec])
+        fig = P.compare_flagged(out, g, ref, rg, oracle_precision=prec)
         figs[prec] = fig
         record_observed(f"{tag} vs {prec}", {
             "unexplained": fig["unexplained"], "radii": fig["radii"], "image_robust_max_rel": fig["image_robust_max_rel"],

@@ -210,6 +210,33 @@ def test_gather_step_with_a_regulariser_outside_the_rasterizer(hip_device, slice
         assert (outs[0][1][k] == outs[1][1][k]).all(), k
 
 
+@pytest.mark.parametrize("slices", [3, 4])
+def test_sliced_gather_step_four_ranks_with_a_regulariser(hip_device, slices):
+    """more than two ranks.  Four gloo ranks (sharing the box's one GPU), one view each, the sliced
+    exchange (all-gather of colour gradients + grouped all-reduce per splat range, issued from inside the backward), a cloud
+    whose size (6000) is no multiple of ranks x 256, slice counts that do (4 x 1536) and do not (3 x 2048) divide it evenly, and
+    a loss term outside the rasterizer: the single-process four-view step's gradients on every rank, bit-identical across the
+    ranks."""
+    assert N % (4 * 256) != 0
+    ref = _reference_grads_regularised(hip_device, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, q, 4, slices, True)) for r in range(4)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in outs) == [0, 1, 2, 3]
+    for rank, g in outs:
+        _close({k: torch.from_numpy(v) for k, v in g.items()}, ref)
+    for k in NAMES:
+        for other in outs[1:]:
+            assert (outs[0][1][k] == other[1][k]).all(), k
+
+
 def test_gather_step_single_rank_with_a_regulariser(hip_device):
     _close(_gather_grads(hip_device, 0, 1, regularise=True), _reference_grads_regularised(hip_device, V))
 

@@ -81,6 +81,31 @@ def test_two_rank_step_equals_single_process_step():
         assert torch.equal(a, b)
 
 
+def test_four_rank_step_with_fewer_views_than_ranks_equals_single_process_step():
+    """world_size 4 over 3 views: rank 3 renders nothing and must still join every collective with zeros; all four ranks end
+    with the single-process gradients (more than two ranks, ragged work)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ref_loss, ref_grads = reference_step()
+    results = sorted(((r, torch.from_numpy(l), [torch.from_numpy(g) for g in gs]) for r, l, gs in results), key=lambda x: x[0])
+    assert [r for r, _, _ in results] == [0, 1, 2, 3]
+    for rank, loss, grads in results:
+        assert torch.allclose(loss, ref_loss, rtol=1e-12, atol=1e-14), rank
+        for g, r in zip(grads, ref_grads):
+            assert torch.allclose(g, r, rtol=1e-10, atol=1e-16), rank
+    for other in results[1:]:
+        for a, b in zip(results[0][2], other[2]):
+            assert torch.equal(a, b)
+
+
 def _avg_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

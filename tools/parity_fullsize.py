@@ -39,7 +39,7 @@ def main():
             for prec in a.precisions.split(","):
                 ref, rg, _ = c_oracle.rasterize(sp, st, use_sh=use_sh, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2],
                                                 threads=threads, precision=prec, fragile=True, margin=a.margin, xy_ulps=a.xy_ulps)
-                fig = P.compare_flagged(out, g, ref, rg)
+                fig = P.compare_flagged(out, g, ref, rg, oracle_precision=prec)
                 line = {"splats": a.splats, "size": [a.width, a.height], "view": view, "path": path, "oracle": prec,
                         "radii": fig["radii"], "unexplained": fig["unexplained"],
                         "conditioning_limited": fig["image_conditioning_limited"],
