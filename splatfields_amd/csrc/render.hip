@@ -19,7 +19,7 @@
 
 namespace sr {
 
-constexpr int kBwdBatch = 128;  // 64 / 96 / 192 / 256 all measured slower (tried and rejected)
+constexpr int kBwdBatch = 128;  // 64 / 96 / 192 / 256 all measured slower (NOTEBOOK.md, tried and rejected)
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -2,7 +2,7 @@
 per-tile lists (membership and order) and the instance accounting.
 
 The kernels emit a (splat, tile) instance only where the splat's alpha >= 1/255 support can reach the tile, inside
-upstream's 3-sigma tile rectangle (the rectangle is clipped to the support's bounding box, and
+upstream's 3-sigma tile rectangle (NOTEBOOK.md section 4 item 2: the rectangle is clipped to the support's bounding box, and
 for rectangles of >= 4 tiles each tile is tested against the ellipse itself).  So, per tile:
   * the HIP list is a subset of the oracle's 3-sigma list, in the same (depth, splat index) order;
   * every oracle entry the HIP list leaves out has alpha < 1/255 on every pixel of the tile (nothing blended is lost);

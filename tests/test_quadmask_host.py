@@ -19,7 +19,7 @@ def test_quad_mask_is_a_tight_superset_of_the_blended_pixels(tmp_path):
 
 def test_reach_mask_packing_of_the_tile_rectangles(tmp_path):
     """Geom::rect carries the small rectangles' reach mask in the top nibbles of its four 12-bit tile coordinates
-    (csrc/common.h): host build of the three helpers, round trip over a million random cases."""
+    (csrc/common.h, NOTEBOOK.md section 4 item 29): host build of the three helpers, round trip over a million random cases."""
     exe = tmp_path / "rectmask_check"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-value", "-o", str(exe),
                     os.path.join(ROOT, "tests", "native", "rectmask_check.hip")], check=True, capture_output=True)
