@@ -139,8 +139,17 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
         const float4* w4 = reinterpret_cast<const float4*>(L.w_packed);
         const int chunk_f4 = L.out_tiles * 128;                // float4 per chunk: mt x 2 x 64
         const int n_chunks = (L.mem_tiles + L.reg_tiles) / 2;
+        // A chunk travels memory -> LDS by LDS-direct loads (global_load_lds_dwordx4: 16 bytes per lane land at consecutive LDS
+        // addresses, no staging registers, no ds_write) that are REQUESTED here and waited for at the top of the next chunk
+        // (lds_copy_wait + barrier): the copy of chunk c + 1 runs under the 128 MFMAs of chunk c.  (Rounds 2-5 loaded the chunk into
+        // registers and stored it: an in-order wavefront sat through the L2 round trip in front of every chunk's MFMAs -- it was
+        // in its MFMA phases 55 % of its life.)
         auto stage = [&](int c, int into) {
-            for (int j = (int)threadIdx.x; j < chunk_f4; j += kBlock) s_w[into][j] = w4[(size_t)c * chunk_f4 + j];
+            const float4* src = w4 + (size_t)c * chunk_f4;
+            for (int j0 = 0; j0 < chunk_f4; j0 += kBlock) {           // chunk_f4 is a multiple of 128: whole wavefronts
+                if (j0 + 64 * wave < chunk_f4)   // (the LDS base is a scalar operand: wave-uniform by construction, told to the compiler)
+                    lds_copy16_async(src + j0 + (int)threadIdx.x, (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_address(&s_w[into][j0 + 64 * wave])));
+            }
         };
         // accumulators start at the bias: rows 4k..4k+3 of output tile mt
 #pragma unroll
@@ -169,7 +178,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
                     const float4 t4 = *reinterpret_cast<const float4*>(L.src + (size_t)prow[nt] * L.src_row + 16 * (2 * c + tl) + 4 * k);
                     bm[tl][nt] = (f32x4){t4.x, t4.y, t4.z, t4.w};
                 }
-            __syncthreads();      // chunk c has landed; the other buffer is free
+            lds_copy_wait();      // this wavefront's pieces of chunk c have landed ...
+            __syncthreads();      // ... and everybody's; the other buffer is free
             if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
@@ -182,6 +192,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(HT 
 #pragma unroll
         for (int cr = 0; cr < HT / 2; ++cr) {
             if (cr < L.reg_tiles / 2) {
+                lds_copy_wait();
                 __syncthreads();
                 if (c + 1 < n_chunks) stage(c + 1, buf ^ 1);
 #pragma unroll
