@@ -655,15 +655,18 @@ class GaussianRasterizer(nn.Module):
 #   * host-side, by identity: the same means3D / means2D / opacities / scales / rotations tensor objects (and `_version`s) and the
 #     same camera tensors and scalar settings as the forward this host thread ran immediately before, shs=None, and a
 #     colors_precomp tensor [N,3] that nothing differentiates;
-#   * device-side, by value: colours all 1 and background all 0 -- checked by a few elementwise kernels whose verdict never
-#     travels to the host: the served image is where(verdict, alpha, NaN).  A caller that passes other colours through this
-#     exact pattern gets NaN, not a wrong mask, and the next call finds the (by then finished) verdict and switches the shortcut
-#     off for the process.
+#   * by value: colours all 1 and background all 0.  The first such call of the process is checked on the host (one
+#     synchronisation, once): if it is something else -- a second pass with per-splat feature colours, say -- the shortcut switches
+#     itself off and the call is rasterized in full, as every later one.  Once the pattern is confirmed the check stays on the
+#     device (a few elementwise kernels whose verdict never travels to the host): the served image is where(verdict, alpha, NaN),
+#     so a later call that breaks the pattern gets NaN, not a wrong mask, and the call after it finds the (by then finished)
+#     verdict and switches the shortcut off for the process.
 # The served tensor is a view of the first pass's alpha output: the mask loss back-propagates into that node's grad_alpha, and
 # the means2D gradient (densification statistics, train.py:280-286) receives both contributions in one backward -- the sum the
 # reference accumulates over its two backward passes.  SPLATRASTER_MASK_SHORTCUT=0 switches it off (two full passes).
 _MASK_SHORTCUT = os.environ.get("SPLATRASTER_MASK_SHORTCUT", "1") not in ("0", "false", "False", "off")
 MASK_CALLS_SERVED = 0   # diagnostics / tests: mask passes answered without a rasterization
+_MASK_CONFIRMED = False  # the pattern has been seen once with white colours on a black background (checked on the host that once)
 
 
 def set_mask_shortcut(enabled: bool) -> bool:
@@ -703,8 +706,17 @@ def _serve_mask_call(rs, means3D, means2D, opacities, shs, colors_precomp, scale
     _check_mask_verdicts()
     if not _MASK_SHORTCUT:
         return None
+    global _MASK_CONFIRMED
     with torch.no_grad():
         ok = (colors_precomp == 1).all() & (rs.bg.to(colors_precomp.device) == 0).all()
+        if not _MASK_CONFIRMED:
+            # The FIRST call of this shape in the process is checked on the host (one synchronisation, once): a caller whose second
+            # call renders something else -- per-splat feature colours behind the RGB pass, say -- never meets the NaN guard; it
+            # simply gets two full passes from here on.
+            if not bool(ok):
+                set_mask_shortcut(False)
+                return None
+            _MASK_CONFIRMED = True
         _note_mask_verdict(ok)
     served = torch.where(ok, alpha, torch.full((), float("nan"), dtype=alpha.dtype, device=alpha.device))
     global MASK_CALLS_SERVED

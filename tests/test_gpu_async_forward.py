@@ -333,11 +333,26 @@ def test_the_reference_mask_pass_is_served_from_the_first_pass(hip_device):
         scale = gref[k].abs().max().item()
         assert torch.allclose(g[k], gref[k], rtol=0, atol=2e-5 * scale), (k, (g[k] - gref[k]).abs().max().item() / scale)
     assert torch.allclose(m2, m2ref, rtol=0, atol=2e-5 * m2ref.abs().max().item())
-    # a call that only LOOKS like the mask pass (other colours) is answered with NaN, never with a wrong mask, and switches
-    # the shortcut off for the process once its verdict has arrived
-    import warnings
+    # a process whose FIRST pattern-shaped call carries other colours (feature rendering behind the RGB pass) never meets the
+    # NaN guard: that call is checked on the host, switches the shortcut off and is rasterized in full
     from diff_gaussian_rasterization import GaussianRasterizer
+    prev, prev_conf = rz.set_mask_shortcut(True), rz._MASK_CONFIRMED
+    try:
+        rz._MASK_CONFIRMED = False
+        p = _leaves(sp)
+        m2_ = torch.zeros_like(p["means3D"], requires_grad=True)
+        kw = dict(means3D=p["means3D"], means2D=m2_, opacities=p["opacities"], scales=p["scales"], rotations=p["rotations"])
+        GaussianRasterizer(_settings(cam, bg))(shs=p["shs"], **kw)
+        feat = GaussianRasterizer(_settings(cam, bg * 0.0))(colors_precomp=torch.full((N, 3), 0.5, device=dev), **kw)[0]
+        assert torch.isfinite(feat).all() and not rz._MASK_SHORTCUT and not rz._MASK_CONFIRMED
+    finally:
+        rz.set_mask_shortcut(prev)
+        rz._MASK_CONFIRMED = prev_conf
+    # once the pattern is confirmed, a call that only LOOKS like the mask pass (other colours) is answered with NaN, never with
+    # a wrong mask, and switches the shortcut off for the process once its verdict has arrived
+    import warnings
     prev = rz.set_mask_shortcut(True)
+    rz._MASK_CONFIRMED = True
     try:
         p = _leaves(sp)
         m2_ = torch.zeros_like(p["means3D"], requires_grad=True)
