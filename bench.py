@@ -801,8 +801,10 @@ def main():
         "stage_ms": stage_ms, "stage_ms_sum": sum(stage_ms.values()),
         # host synchronisations of the forward inside the timed region (sr_debug_counters): forwards that waited for their
         # instance count (sr_forward: first render of a camera) vs forwards launched without waiting (sr_forward_async)
-        "host_sync": dict(host_sync, async_forward=rz.async_forward_enabled(),
-                          note="timed steps only; the cameras of the cycle were rendered before, so no forward should wait"),
+        "host_sync": dict(host_sync, async_forward="opt-in inside the step (checked_forward: async_forward() + resolve_pending())",
+                          note="timed steps only; the cameras of the cycle were rendered before, so no forward waits MID-forward: each "
+                               "step's ticket is redeemed before its backward (tickets_waited_for counts the redemptions that found "
+                               "stage 1 still running)"),
         # algorithmic bytes of every stage / its measured duration, as a fraction of the 8 TB/s HBM peak
         "stage_hbm_frac": {k: (stage_bytes(k, N, vis, R, H * W, c_in) / (v * 1e-3) / HBM_PEAK if v > 0 else None) for k, v in stage_ms.items()},
     }

@@ -77,7 +77,11 @@ def test_headline_config_images_and_all_gradients_against_c_oracle(hip_device, v
       * non-fragile pixels <= 1e-4 relative (+ the oracle's bound for float rounding of the splats' stored centres),
       * gradient elements beyond 1e-3 of the tensor's maximum only on splats blended into a fragile pixel,
       * radii equal except where the ceil's argument is within rounding of an integer."""
+    import os
     from tests.helpers import assert_parity_explained
+    if (os.cpu_count() or 1) < 32 and view not in (0, 7):
+        # four oracle passes per view at 1 M splats take seconds on the GPU boxes' 256 host threads and minutes on a handful
+        pytest.skip("host with < 32 hardware threads: the full-size oracle comparison runs for views 0 and 7 only")
     sp, cam, st, grads = make_scene(1_000_000, 800, 800, view=view)
     for use_sh in (True, False):
         out, g = run_hip(sp, st, grads, hip_device, use_sh=use_sh)
