@@ -770,6 +770,12 @@ def main():
     tj, traffic_why = recorded_counters("traffic.json", wl)   # PMC bytes of this workload and these kernel sources only
     dom = max(stage_ms, key=stage_ms.get)
     traffic = tj.get(dom) if tj else None
+    if traffic is not None and traffic_why is None:
+        # the guide calibrates the x 2 FETCH_SIZE correction on wide coalesced streaming reads; the blend
+        # kernels' reads are 64-byte record gathers, for which the corrected figure is an UPPER bound of the bytes moved
+        traffic_why = ("bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes (profiles/traffic.json); "
+                       "the x 2 read correction of MI355X_MICROARCH.md is calibrated for wide coalesced streaming reads -- for the "
+                       "gather-dominated blend kernels it makes this an upper bound")
 
     out = {
         "metric": "splats*px rasterized/sec (fwd+bwd)", "value": value, "unit": "splat*px/s", "n_gpus": world,
