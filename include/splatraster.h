@@ -177,15 +177,17 @@ int sr_ticket_release(void* ticket);
 /* Backward of both stages.  dL_ddepth / dL_dalpha may be NULL (treated as zero).  `instances` is the capacity the binning
  * buffer was rendered with; `scratch` holds sr_backward_scratch_bytes(instances) bytes.
  * `instances_rendered`: the instance count the forward reported for these buffers (*instances_out), or -1 if the caller did
- * not keep it.  It only selects between the two backward blend kernels, which produce the same gradient slots: small
- * footprints (fewer than SR_BWD_WAVE_KERNEL_ABOVE instances per splat) replay on the entry-per-lane kernel (quad buckets, DPP
- * scans: blend_bwd.hip), large footprints on the pixel-per-lane kernel (render.hip); unknown = the former.
+ * not keep it.  It only selects a variant of the per-splat reduction (fewer than SR_BWD_SLOT_SPEC_BELOW instances per splat on
+ * average, or unknown: a splat's first gradient slots are requested together with their `reached` bytes); the results are the
+ * same.  (Rounds 2-5 also switched the backward BLEND kernel on it; since round 6 the entry-per-lane kernel -- quad buckets,
+ * DPP scans: blend_bwd.hip -- runs at every footprint, and the pixel-per-lane kernel of render.hip is kept as a second
+ * implementation of the same gradient slots: sr_set_backward_kernel.)
  * `binning` is NOT const: the backward blend sets, inside it, one `reached` byte per tile-splat instance it wrote a gradient
  * slot for (the forward's scatter cleared them), and the per-splat reduction reads them back.  Consequences for callers:
  * ONE backward at a time per set of forward buffers (two concurrent backwards on the same buffers -- different streams or
  * host threads -- race on those bytes), a backward may be REPEATED on the same buffers (it sets the same bytes again:
  * `retain_graph=True` works), and a copy of the binning buffer taken before a backward is a valid input of another one. */
-#define SR_BWD_WAVE_KERNEL_ABOVE 6
+#define SR_BWD_SLOT_SPEC_BELOW 6
 int sr_backward(const SrView* view, const SrSplats* splats, const void* geom, void* binning,
                 long long instances, long long instances_rendered, const void* image, const int* radii,
                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,

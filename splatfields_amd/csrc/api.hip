@@ -469,13 +469,16 @@ int backward_impl(int what, const SrView* view, const SrSplats* splats, const vo
     float* slots = static_cast<float*>(scratch);
     if (what & 1) {
         StageTimer t_(5, st);
-        // Two kernels, one slot format.  Entry-per-lane (MFMA moment reduction) wins while a splat reaches few pixels of a tile
-        // (measured on MI355X, 800x800: 0.286 vs 0.370 ms at 2.3 instances per splat, 0.207 vs 0.215 at 4.6); pixel-per-lane
-        // (wave butterflies) wins once most lanes of an 8x8 sub-tile are inside the footprint (0.192 vs 0.203 at 7.4, 0.182 vs
-        // 0.203 at 15).  SPLATRASTER_BWD=wave|quads pins one of them (A/B measurements; "mfma", the name of rounds 2-3, is accepted for "quads").
+        // Two kernels, one slot format.  The entry-per-lane kernel over 4x4 quads (blend_bwd.hip) is the product path at EVERY
+        // footprint.  (Round 2 measured a crossover -- pixel-per-lane 0.192 vs 0.203 ms at 7.4 instances per splat, 0.182 vs 0.203
+        // at 15 -- and rounds 2-5 switched kernels at SR_BWD_SLOT_SPEC_BELOW instances per splat.  Re-measured in round 6, after
+        // three rounds of work on the quad kernel only (MI355X, 800x800, ms of the backward blend, quads vs pixel-per-lane): 4.6
+        // instances per splat 0.156 vs 0.262, 7.4: 0.136 vs 0.212, 15: 0.129 vs 0.186, 67: 0.157 vs 0.210, 225: 0.182 vs 0.211,
+        // 715: 0.163 vs 0.179, 1270: 0.168 vs 0.171.)  The pixel-per-lane kernel (render.hip) stays as an independently written
+        // second implementation of the same slots: SPLATRASTER_BWD=wave / sr_set_backward_kernel(1) select it, the tests and
+        // tools/fuzz_backward.py compare the two ("mfma", the name of rounds 2-3, is accepted for "quads").
         const int pinned = g_bwd_kernel.load(std::memory_order_relaxed);   // sr_set_backward_kernel / SPLATRASTER_BWD at load time
-        const bool dense = instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N;
-        const bool wave_kernel = pinned ? pinned == 1 : dense;
+        const bool wave_kernel = pinned == 1;
         if (wave_kernel) sr::launch_render_backward(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
         else sr::launch_render_backward_quads(v, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, slots, st);
     }
@@ -488,9 +491,9 @@ int backward_impl(int what, const SrView* view, const SrSplats* splats, const vo
         gr.shs = s.shs ? grads->dL_dshs : nullptr;
         gr.shs_rest = (s.shs_rest && gr.shs) ? grads->dL_dshs_rest : nullptr;
         gr.colors = (s.colors || (s.shs && !grads->dL_dshs)) ? grads->dL_dcolors : nullptr;  // SH input + colours only: colour-gradient mode
-        // small footprints (the rule of the blend kernel above; unknown counts as small): the variant that requests a splat's
-        // first gradient slots together with their `reached` bytes
-        const bool small_fp = !(instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_WAVE_KERNEL_ABOVE * (long long)s.N);
+        // small footprints (fewer than SR_BWD_SLOT_SPEC_BELOW instances per splat on average; unknown counts as small): the
+        // variant that requests a splat's first gradient slots together with their `reached` bytes
+        const bool small_fp = !(instances_rendered >= 0 && instances_rendered > (long long)SR_BWD_SLOT_SPEC_BELOW * (long long)s.N);
         { StageTimer t_(6, st); sr::launch_preprocess_backward(v, s, g, radii, slots, b.reached, gr, first, count, small_fp, st); }
         SR_TRY(after_launch(view, st, "preprocess_backward"));
     }

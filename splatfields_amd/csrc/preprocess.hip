@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_preprocess_backward(const ViewK v, c
     // out of the chain is time.
     uint32_t reached4 = 0u;
     // Only for small footprints -- a template parameter, chosen by the host with the rule that picks the backward blend kernel (at
-    // most SR_BWD_WAVE_KERNEL_ABOVE instances per splat on average): with 15 instances per splat (300 k x 0.02) the speculative
+    // most SR_BWD_SLOT_SPEC_BELOW instances per splat on average): with 15 instances per splat (300 k x 0.02) the speculative
     // form is SLOWER, 0.0787 vs 0.0680 ms (most of a splat's slots are then fetched by the loop below anyway), and a run-time
     // switch inside one kernel costs the dense case 7 us of its own (0.0749: the speculative registers stay allocated).
     constexpr bool use_spec = SPEC;

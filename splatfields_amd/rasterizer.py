@@ -138,8 +138,9 @@ _BWD_KERNELS = {None: 0, "auto": 0, "wave": 1, "quads": 2, "mfma": 2}   # "mfma"
 
 
 def set_backward_kernel(which) -> str:
-    """Pin the backward blend kernel (A/B measurements, the test that compares the two): None / "auto" = chosen per launch by
-    the footprint, "wave" = pixel-per-lane, "quads" = entry-per-lane (quad buckets).  Returns the previous setting."""
+    """Pin the backward blend kernel (A/B measurements, the test that compares the two): None / "auto" = the product choice
+    (entry-per-lane over quad buckets at every footprint since round 6), "wave" = pixel-per-lane (round 1's kernel, kept as a
+    second implementation of the same gradient slots), "quads" = entry-per-lane.  Returns the previous setting."""
     prev = _lib.load().sr_set_backward_kernel(_BWD_KERNELS[which])
     return {0: "auto", 1: "wave", 2: "quads"}[prev]
 
