@@ -117,3 +117,52 @@ def test_means2d_gradient_is_ndc_scaled():
     g_m2, g_pix = torch.autograd.grad(loss, [m2, pix])
     assert torch.allclose(g_m2[:, 0], g_pix[:, 0] * 0.5 * 48) and torch.allclose(g_m2[:, 1], g_pix[:, 1] * 0.5 * 32)
     assert (g_m2[:, 2] == 0).all()
+
+
+def test_c_oracle_in_double_equals_the_fp64_torch_oracle():
+    """Round 6: the C restatement exists in float (the published arithmetic) and in double (-DREF_REAL=double, the reference of
+    the full-size comparisons).  In double it must reproduce the independent fp64 autograd oracle to the rounding of its float
+    outputs -- images, radii, instance count and every gradient (explicit backward vs autograd)."""
+    sp, cam, st, grads = make_scene(4000, 144, 112, mean_scale=0.05)
+    out, gr, nr = c_oracle.rasterize(sp, st, use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], precision="fp64", threads=4)
+    ref, gref = O.fwd_bwd(sp, st, *grads, use_sh=True, dtype=torch.float64)
+    assert nr == ref.num_rendered and int((out["radii"] != ref.radii).sum()) == 0
+    for k, r in (("color", ref.color), ("depth", ref.depth), ("alpha", ref.alpha)):
+        robust, frag = image_errors(out[k], r.detach(), ref.fragile)
+        assert robust < 2e-6 and frag < 2e-2, (k, robust, frag)     # float outputs of a double computation
+    for k in gr:
+        assert grad_error(gr[k], gref[k]) < 2e-6, (k, grad_error(gr[k], gref[k]))
+    # precomputed-colour path
+    out2, gr2, _ = c_oracle.rasterize(sp, st, use_sh=False, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], precision="fp64", threads=4)
+    ref2, gref2 = O.fwd_bwd(sp, st, *grads, use_sh=False, dtype=torch.float64)
+    for k in gr2:
+        assert grad_error(gr2[k], gref2[k]) < 2e-6, k
+
+
+def test_c_oracle_fragile_accounting_explains_float_vs_double():
+    """The C oracle's account of what two fp32 evaluations may differ in (oracle/raster_ref.c: fragile pixels, flagged splats,
+    rectangle decisions, the conditioning bound) applied to ITS OWN float build against its double build -- the float oracle
+    is an fp32 evaluation like the HIP path: nothing may stay unexplained, the fragile mask must contain the torch oracle's,
+    and the analysis must not change the float build's results."""
+    from oracle import parity as P
+    sp, cam, st, grads = make_scene(20000, 256, 256)
+    kw = dict(use_sh=True, g_img=grads[0], g_depth=grads[1], g_alpha=grads[2], threads=8)
+    o32, g32, _ = c_oracle.rasterize(sp, st, **kw)
+    o32f, g32f, _ = c_oracle.rasterize(sp, st, fragile=True, **kw)
+    for k in ("color", "depth", "alpha", "radii"):
+        assert torch.equal(o32[k], o32f[k]), k                          # the analysis is read-only
+    r64, rg64, _ = c_oracle.rasterize(sp, st, precision="fp64", fragile=True, xy_ulps=4.0, **kw)
+    fig = P.compare_flagged(o32, g32, r64, rg64, oracle_precision="fp64")
+    assert fig["unexplained"] == 0, fig
+    assert fig["radii"]["unexplained"] == 0
+    assert 0.0 < fig["images"]["color"]["fragile_share"] < 0.05          # a small scene: few near-threshold pixels
+    assert 0.0 < fig["flagged_splat_share"] < 0.6
+    assert fig["gradient_max_unflagged"] < 1e-3
+    ref = O.rasterize(sp["means3D"].double(), None, sp["opacities"].double(), shs=sp["shs"].double(), scales=sp["scales"].double(),
+                      rotations=sp["rotations"].double(), settings=st)
+    assert not (ref.fragile & ~r64["fragile"]).any()                     # same margins + the depth-tie and rectangle rules
+    cb = r64["cond_bound"]
+    assert cb.shape == (5, 256, 256) and (cb >= 0).all() and float(cb.max()) < 1e-3 and float(cb.mean()) < 2e-5
+    assert r64["splat_flag"].dtype == torch.bool and r64["radius_raw"].shape == (20000,)
+    vis = o32["radii"] > 0
+    assert torch.equal(torch.ceil(r64["radius_raw"][vis]).to(torch.int32), r64["radii"][vis])
