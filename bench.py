@@ -788,7 +788,10 @@ def main():
                   "costs the stream several microseconds: they read slightly higher than ms_per_step).  The timed step launches its "
                   "forward without the mid-forward host wait (sr_forward_async) and redeems the ticket before the backward: "
                   "value assumes a 100 % hit rate of the capacity / list-length promises (static splats, cameras rendered before); "
-                  "ms_per_step_sync_forward = the same K steps with every forward waiting on the host (the plain facade's default)",
+                  "ms_per_step_sync_forward = the same K steps with every forward waiting on the host (the plain facade's default).  "
+                  "The splat parameters are the same tensors in every step (synthetic inputs resident in HBM, no optimizer between the "
+                  "steps), so part of the 192 MB SH tensor survives in the 256 MB Infinity Cache from step to step: an optimizer "
+                  "update between two steps costs the forward preprocess ~3 us of this figure (NOTEBOOK.md section 9.10)",
         "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{N} synthetic splats (seed 1234), {W}x{H}, {'SH degree %d' % args.sh_degree if use_sh else 'precomputed colours'}, "
